@@ -1,0 +1,69 @@
+// Shared host/device helpers of the adcdiff HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/adcdiff.h"
+
+namespace adcdiff {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Thread-local message for adcdiff_last_error().
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+
+inline hipStream_t as_stream(adcdiff_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return ADCDIFF_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+// ---------------------------------------------------------------- Philox4x32-10 noise
+// counter = (col / 4, row, step, stream), key = (seed lo, seed hi); the four output words give the
+// four normals of columns 4q..4q+3 by two Box-Muller pairs (see oracle/philox.py for the definition).
+__device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
+                                              uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, float& z0, float& z1) {
+    const float u1 = (float)((wa >> 8) + 1u) * 5.9604644775390625e-8f;   // (0, 1], exact
+    const float u2 = (float)(wb >> 8) * 5.9604644775390625e-8f;          // [0, 1), exact
+    // v_log_f32 is log2; v_sin/v_cos take their argument in revolutions, so 2*pi*u2 is never formed
+    const float radius = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    z0 = radius * __builtin_amdgcn_cosf(u2);
+    z1 = radius * __builtin_amdgcn_sinf(u2);
+}
+
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint32_t stream, uint32_t step, uint64_t row,
+                                                uint32_t quad) {
+    uint32_t c0 = quad, c1 = (uint32_t)row, c2 = step, c3 = stream;
+    philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+    f32x4 z;
+    float a, b;
+    box_muller(c0, c1, a, b); z[0] = a; z[1] = b;
+    box_muller(c2, c3, a, b); z[2] = a; z[3] = b;
+    return z;
+}
+
+}  // namespace adcdiff

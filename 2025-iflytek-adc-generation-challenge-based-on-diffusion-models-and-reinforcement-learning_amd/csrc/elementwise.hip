@@ -1,0 +1,368 @@
+// HBM-bound kernels of the DDPM path: GroupNorm+SiLU, the fused schedule update (posterior mean,
+// variance, Philox noise), DDIM update, q_sample, Philox fill, and the small table helpers.
+// Built with -ffp-contract=off so that the update formulas round exactly like the reference's
+// separate float32 torch ops.
+#include "common.h"
+
+namespace adcdiff {
+
+char* error_buffer() {
+    static thread_local char buf[512] = "";
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ------------------------------------------------------------------ GroupNorm + SiLU
+// One float4 (four channels) per thread; a group of gs channels spans gs/4 adjacent lanes, so the two
+// statistics passes (mean, then centred sum of squares) are xor-shuffle reductions over gs/4 lanes.
+// Reads x once, fully coalesced; writes the activation (and optionally a converted copy of x).
+template <typename OutT>
+__global__ __launch_bounds__(256) void gn_silu_vec_kernel(const float* __restrict__ x, int ldx, long total4, int c4,
+                                                          int lanes_per_group, float inv_gs, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, OutT* __restrict__ out,
+                                                          int ldo, OutT* __restrict__ raw, int ldraw) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = e < total4;
+    const long ee = live ? e : 0;
+    const long row = ee / c4;
+    const int col = (int)(ee - row * c4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + col);
+    float s = (v[0] + v[1]) + (v[2] + v[3]);
+    for (int m = 1; m < lanes_per_group; m <<= 1) s += __shfl_xor(s, m);
+    const float mean = s * inv_gs;
+    const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+    float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    for (int m = 1; m < lanes_per_group; m <<= 1) q += __shfl_xor(q, m);
+    const float rstd = 1.0f / __builtin_sqrtf(q * inv_gs + eps);
+    if (!live) return;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + col);
+    f32x4 y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = silu_f(d[i] * rstd * g[i] + b[i]);
+    if constexpr (sizeof(OutT) == 4) {
+        *reinterpret_cast<f32x4*>(out + row * ldo + col) = y;
+        if (raw) *reinterpret_cast<f32x4*>(raw + row * ldraw + col) = v;
+    } else {
+        bf16x4 o = {(bf16_t)y[0], (bf16_t)y[1], (bf16_t)y[2], (bf16_t)y[3]};
+        *reinterpret_cast<bf16x4*>(out + row * ldo + col) = o;
+        if (raw) {
+            bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(raw + row * ldraw + col) = r;
+        }
+    }
+}
+
+// Any group size: one thread per (row, group), serial over the group's channels.
+template <typename OutT>
+__global__ __launch_bounds__(256) void gn_silu_generic_kernel(const float* __restrict__ x, int ldx, long total_groups, int groups,
+                                                              int gs, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float eps, OutT* __restrict__ out, int ldo, OutT* __restrict__ raw,
+                                                              int ldraw) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total_groups) return;
+    const long row = e / groups;
+    const int c0 = (int)(e - row * groups) * gs;
+    const float* xr = x + row * ldx + c0;
+    float s = 0.0f;
+    for (int i = 0; i < gs; ++i) s += xr[i];
+    const float mean = s / (float)gs;
+    float q = 0.0f;
+    for (int i = 0; i < gs; ++i) { const float d = xr[i] - mean; q += d * d; }
+    const float rstd = 1.0f / __builtin_sqrtf(q / (float)gs + eps);
+    for (int i = 0; i < gs; ++i) {
+        const float y = silu_f((xr[i] - mean) * rstd * gamma[c0 + i] + beta[c0 + i]);
+        out[row * ldo + c0 + i] = (OutT)y;
+        if (raw) raw[row * ldraw + c0 + i] = (OutT)xr[i];
+    }
+}
+
+template <typename OutT>
+static int gn_launch(const float* x, int ldx, int M, int C, int groups, const float* gamma, const float* beta, float eps,
+                     OutT* out, int ldo, OutT* raw, int ldraw, hipStream_t stream) {
+    const int gs = C / groups;
+    const bool pow2 = (gs & (gs - 1)) == 0;
+    const bool vec = pow2 && gs >= 4 && gs <= 256 && (ldx % 4 == 0) && (ldo % 4 == 0) && (!raw || ldraw % 4 == 0) &&
+                     aligned16(x) && aligned16(gamma) && aligned16(beta) && ((reinterpret_cast<uintptr_t>(out) & 7u) == 0) &&
+                     (sizeof(OutT) == 2 || (aligned16(out) && (!raw || aligned16(raw)))) && (!raw || (reinterpret_cast<uintptr_t>(raw) & 7u) == 0);
+    if (vec) {
+        const long total4 = (long)M * (C / 4);
+        const long blocks = (total4 + 255) / 256;
+        hipLaunchKernelGGL((gn_silu_vec_kernel<OutT>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, total4, C / 4, gs / 4,
+                           1.0f / (float)gs, gamma, beta, eps, out, ldo, raw, ldraw);
+    } else {
+        const long total = (long)M * groups;
+        const long blocks = (total + 255) / 256;
+        hipLaunchKernelGGL((gn_silu_generic_kernel<OutT>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, total, groups, gs,
+                           gamma, beta, eps, out, ldo, raw, ldraw);
+    }
+    return check_launch("groupnorm_silu");
+}
+
+int groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const float* gamma, const float* beta, float eps,
+                   int out_dtype, void* out, int ldo, void* raw_out, int ldraw, hipStream_t stream) {
+    if (!x || !gamma || !beta || !out || M <= 0 || C <= 0 || groups <= 0 || C % groups != 0 || ldx < C || ldo < C)
+        return fail(ADCDIFF_E_BADARG, "groupnorm_silu: bad arguments (M=%d C=%d groups=%d ldx=%d ldo=%d)", M, C, groups, ldx, ldo);
+    if (raw_out && ldraw < C) return fail(ADCDIFF_E_BADARG, "groupnorm_silu: ldraw=%d < C=%d", ldraw, C);
+    if (out_dtype == ADCDIFF_F32)
+        return gn_launch<float>(x, ldx, M, C, groups, gamma, beta, eps, reinterpret_cast<float*>(out), ldo,
+                                reinterpret_cast<float*>(raw_out), ldraw, stream);
+    if (out_dtype == ADCDIFF_BF16)
+        return gn_launch<bf16_t>(x, ldx, M, C, groups, gamma, beta, eps, reinterpret_cast<bf16_t*>(out), ldo,
+                                 reinterpret_cast<bf16_t*>(raw_out), ldraw, stream);
+    return fail(ADCDIFF_E_BADARG, "groupnorm_silu: unknown dtype %d", out_dtype);
+}
+
+// ------------------------------------------------------------------ Philox fill
+__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, int ld, long total4, int q4, uint64_t seed,
+                                                            uint32_t stream_id, uint32_t step, uint64_t row_offset) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total4) return;
+    const long row = e / q4;
+    const int quad = (int)(e - row * q4);
+    const f32x4 z = philox_normal4(seed, stream_id, step, row_offset + (uint64_t)row, (uint32_t)quad);
+    *reinterpret_cast<f32x4*>(out + row * ld + quad * 4) = z;
+}
+
+// ------------------------------------------------------------------ schedule update (one reverse step)
+// mean = sra * (x - beta * eps / s1m); out = mean + sigma * z.  12 bytes of HBM traffic per element with
+// in-kernel noise (read x, read eps, write out), 16 with injected noise.
+template <bool INJECT>
+__global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ eps, int lde,
+                                                        const float* __restrict__ noise, int ldn, float* __restrict__ out, int ldo,
+                                                        long total4, int q4, adcdiff_ddpm_coef c, uint64_t seed, uint32_t step,
+                                                        uint64_t row_offset) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total4) return;
+    const long row = e / q4;
+    const int quad = (int)(e - row * q4);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + quad * 4);
+    const f32x4 ev = *reinterpret_cast<const f32x4*>(eps + row * lde + quad * 4);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = c.sqrt_recip_alpha * (xv[i] - (c.beta * ev[i]) / c.sqrt_one_minus_ac);
+    if (c.sigma != 0.0f) {
+        f32x4 z;
+        if constexpr (INJECT) z = *reinterpret_cast<const f32x4*>(noise + row * ldn + quad * 4);
+        else z = philox_normal4(seed, ADCDIFF_STREAM_STEP, step, row_offset + (uint64_t)row, (uint32_t)quad);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = o[i] + c.sigma * z[i];
+    }
+    *reinterpret_cast<f32x4*>(out + row * ldo + quad * 4) = o;
+}
+
+template <bool INJECT>
+__global__ __launch_bounds__(256) void ddim_step_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ eps, int lde,
+                                                        const float* __restrict__ noise, int ldn, float* __restrict__ out, int ldo,
+                                                        long total4, int q4, adcdiff_ddim_coef c, uint64_t seed, uint32_t step,
+                                                        uint64_t row_offset) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total4) return;
+    const long row = e / q4;
+    const int quad = (int)(e - row * q4);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + quad * 4);
+    const f32x4 ev = *reinterpret_cast<const f32x4*>(eps + row * lde + quad * 4);
+    f32x4 dir;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dir[i] = c.dir_coef * ev[i];
+    if (c.sigma != 0.0f) {
+        f32x4 z;
+        if constexpr (INJECT) z = *reinterpret_cast<const f32x4*>(noise + row * ldn + quad * 4);
+        else z = philox_normal4(seed, ADCDIFF_STREAM_STEP, step, row_offset + (uint64_t)row, (uint32_t)quad);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dir[i] = dir[i] + c.sigma * z[i];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float pred_x0 = (xv[i] - c.c_eps * ev[i]) / c.sqrt_ac_t;
+        o[i] = c.sqrt_ac_prev * pred_x0 + dir[i];
+    }
+    *reinterpret_cast<f32x4*>(out + row * ldo + quad * 4) = o;
+}
+
+template <bool INJECT>
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, int ldx, const int64_t* __restrict__ t,
+                                                       const float* __restrict__ sqrt_ac, const float* __restrict__ sqrt_1mac,
+                                                       const float* __restrict__ noise, int ldn, float* __restrict__ out, int ldo,
+                                                       float* __restrict__ noise_out, int ldno, long total4, int q4, uint64_t seed,
+                                                       uint32_t step, uint64_t row_offset) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total4) return;
+    const long row = e / q4;
+    const int quad = (int)(e - row * q4);
+    const long tr = t[row];
+    const float a = sqrt_ac[tr], s = sqrt_1mac[tr];
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x0 + row * ldx + quad * 4);
+    f32x4 z;
+    if constexpr (INJECT) z = *reinterpret_cast<const f32x4*>(noise + row * ldn + quad * 4);
+    else z = philox_normal4(seed, ADCDIFF_STREAM_QNOISE, step, row_offset + (uint64_t)row, (uint32_t)quad);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = a * xv[i] + s * z[i];
+    *reinterpret_cast<f32x4*>(out + row * ldo + quad * 4) = o;
+    if (noise_out) *reinterpret_cast<f32x4*>(noise_out + row * ldno + quad * 4) = z;
+}
+
+static bool rowvec_ok(const void* p, int ld, int D) { return p && aligned16(p) && ld >= D && ld % 4 == 0; }
+
+// ------------------------------------------------------------------ table helpers
+// sinusoid[t, j] = sin(t * freq[j]) for j < half, cos(t * freq[j - half]) above (diffusion_model.py:815-816).
+__global__ __launch_bounds__(256) void sinusoid_kernel(float* __restrict__ out, int ld, int rows, int half,
+                                                       const float* __restrict__ freq) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rows * half) return;
+    const int t = (int)(e / half), j = (int)(e - (long)t * half);
+    const float arg = (float)t * freq[j];
+    out[(long)t * ld + j] = sinf(arg);
+    out[(long)t * ld + half + j] = cosf(arg);
+}
+
+// s[r, :] = SiLU(te_table[t_r, :] + cemb[r, :]) in the GEMM operand type: the A operand of time_proj
+// (diffusion_model.py:766, 859-862) when a condition makes the time term row dependent.
+template <typename OutT>
+__global__ __launch_bounds__(256) void temb_silu_kernel(const float* __restrict__ te_table, int ldt, const int64_t* __restrict__ t_rows,
+                                                        int t_uniform, const float* __restrict__ cemb, int ldce,
+                                                        OutT* __restrict__ out, int ldo, int rows, int H) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rows * H) return;
+    const long r = e / H;
+    const int j = (int)(e - r * H);
+    const long t = t_rows ? (long)t_rows[r] : (t_uniform < 0 ? r : (long)t_uniform);   // t_uniform < 0: row r is timestep r
+    float v = te_table[t * ldt + j];
+    if (cemb) v = v + cemb[r * ldce + j];
+    out[r * ldo + j] = (OutT)silu_f(v);
+}
+
+// dst[n, col0 + k] = (T) src[n, k]: packs float32 nn.Linear weights into a K-concatenated operand.
+template <typename OutT>
+__global__ __launch_bounds__(256) void cast_pack_kernel(const float* __restrict__ src, int lds_, OutT* __restrict__ dst, int ldd,
+                                                        int col0, int rows, int cols) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rows * cols) return;
+    const long r = e / cols;
+    const int k = (int)(e - r * cols);
+    dst[r * ldd + col0 + k] = (OutT)src[r * lds_ + k];
+}
+
+__global__ __launch_bounds__(256) void add_vec_kernel(const float* a, const float* b, float* out, int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n) out[e] = a[e] + (b ? b[e] : 0.0f);
+}
+
+int sinusoid_table(float* out, int ld, int rows, int half, const float* freq, hipStream_t stream) {
+    const long total = (long)rows * half;
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, out, ld, rows, half, freq);
+    return check_launch("sinusoid");
+}
+
+int temb_silu(const float* te_table, int ldt, const int64_t* t_rows, int t_uniform, const float* cemb, int ldce, int dtype,
+              void* out, int ldo, int rows, int H, hipStream_t stream) {
+    const long total = (long)rows * H;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == ADCDIFF_BF16)
+        hipLaunchKernelGGL((temb_silu_kernel<bf16_t>), grid, dim3(256), 0, stream, te_table, ldt, t_rows, t_uniform, cemb, ldce,
+                           reinterpret_cast<bf16_t*>(out), ldo, rows, H);
+    else
+        hipLaunchKernelGGL((temb_silu_kernel<float>), grid, dim3(256), 0, stream, te_table, ldt, t_rows, t_uniform, cemb, ldce,
+                           reinterpret_cast<float*>(out), ldo, rows, H);
+    return check_launch("temb_silu");
+}
+
+int cast_pack(const float* src, int lds_, int dtype, void* dst, int ldd, int col0, int rows, int cols, hipStream_t stream) {
+    const long total = (long)rows * cols;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == ADCDIFF_BF16)
+        hipLaunchKernelGGL((cast_pack_kernel<bf16_t>), grid, dim3(256), 0, stream, src, lds_, reinterpret_cast<bf16_t*>(dst), ldd, col0,
+                           rows, cols);
+    else
+        hipLaunchKernelGGL((cast_pack_kernel<float>), grid, dim3(256), 0, stream, src, lds_, reinterpret_cast<float*>(dst), ldd, col0,
+                           rows, cols);
+    return check_launch("cast_pack");
+}
+
+int add_vec(const float* a, const float* b, float* out, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(add_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a, b, out, n);
+    return check_launch("add_vec");
+}
+
+}  // namespace adcdiff
+
+using namespace adcdiff;
+
+extern "C" int adcdiff_abi_version(void) { return ADCDIFF_ABI_VERSION; }
+extern "C" const char* adcdiff_last_error(void) { return error_buffer(); }
+
+extern "C" int adcdiff_groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const float* gamma, const float* beta,
+                                      float eps, int out_dtype, void* out, int ldo, void* raw_out, int ldraw,
+                                      adcdiff_stream_t stream) {
+    return groupnorm_silu(x, ldx, M, C, groups, gamma, beta, eps, out_dtype, out, ldo, raw_out, ldraw, as_stream(stream));
+}
+
+extern "C" int adcdiff_philox_normal(float* out, int ld, int rows, int cols, uint64_t seed, uint32_t stream_id, uint32_t step,
+                                     uint64_t row_offset, adcdiff_stream_t stream) {
+    if (rows <= 0 || cols <= 0 || cols % 4 != 0 || !rowvec_ok(out, ld, cols))
+        return fail(ADCDIFF_E_BADARG, "philox_normal: rows=%d cols=%d (multiple of 4) ld=%d", rows, cols, ld);
+    const long total4 = (long)rows * (cols / 4);
+    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream), out, ld, total4,
+                       cols / 4, seed, stream_id, step, row_offset);
+    return check_launch("philox_normal");
+}
+
+extern "C" int adcdiff_ddpm_step(const float* x, int ldx, const float* eps, int lde, const float* noise, int ldn, float* out, int ldo,
+                                 int B, int D, adcdiff_ddpm_coef coef, uint64_t seed, uint32_t step, uint64_t row_offset,
+                                 adcdiff_stream_t stream) {
+    if (B <= 0 || D <= 0 || D % 4 != 0 || !rowvec_ok(x, ldx, D) || !rowvec_ok(eps, lde, D) || !rowvec_ok(out, ldo, D) ||
+        (noise && !rowvec_ok(noise, ldn, D)))
+        return fail(ADCDIFF_E_BADARG, "ddpm_step: B=%d D=%d (multiple of 4), pointers 16-byte aligned, ld >= D", B, D);
+    const long total4 = (long)B * (D / 4);
+    const dim3 grid((unsigned)((total4 + 255) / 256));
+    if (noise)
+        hipLaunchKernelGGL((ddpm_step_kernel<true>), grid, dim3(256), 0, as_stream(stream), x, ldx, eps, lde, noise, ldn, out, ldo,
+                           total4, D / 4, coef, seed, step, row_offset);
+    else
+        hipLaunchKernelGGL((ddpm_step_kernel<false>), grid, dim3(256), 0, as_stream(stream), x, ldx, eps, lde, noise, ldn, out, ldo,
+                           total4, D / 4, coef, seed, step, row_offset);
+    return check_launch("ddpm_step");
+}
+
+extern "C" int adcdiff_ddim_step(const float* x, int ldx, const float* eps, int lde, const float* noise, int ldn, float* out, int ldo,
+                                 int B, int D, adcdiff_ddim_coef coef, uint64_t seed, uint32_t step, uint64_t row_offset,
+                                 adcdiff_stream_t stream) {
+    if (B <= 0 || D <= 0 || D % 4 != 0 || !rowvec_ok(x, ldx, D) || !rowvec_ok(eps, lde, D) || !rowvec_ok(out, ldo, D) ||
+        (noise && !rowvec_ok(noise, ldn, D)))
+        return fail(ADCDIFF_E_BADARG, "ddim_step: B=%d D=%d (multiple of 4), pointers 16-byte aligned, ld >= D", B, D);
+    const long total4 = (long)B * (D / 4);
+    const dim3 grid((unsigned)((total4 + 255) / 256));
+    if (noise)
+        hipLaunchKernelGGL((ddim_step_kernel<true>), grid, dim3(256), 0, as_stream(stream), x, ldx, eps, lde, noise, ldn, out, ldo,
+                           total4, D / 4, coef, seed, step, row_offset);
+    else
+        hipLaunchKernelGGL((ddim_step_kernel<false>), grid, dim3(256), 0, as_stream(stream), x, ldx, eps, lde, noise, ldn, out, ldo,
+                           total4, D / 4, coef, seed, step, row_offset);
+    return check_launch("ddim_step");
+}
+
+extern "C" int adcdiff_q_sample(const float* x0, int ldx, const int64_t* t, const float* sqrt_ac, const float* sqrt_one_minus_ac,
+                                int num_timesteps, const float* noise, int ldn, float* out, int ldo, float* noise_out, int ldno,
+                                int B, int D, uint64_t seed, uint32_t step, uint64_t row_offset, adcdiff_stream_t stream) {
+    if (B <= 0 || D <= 0 || D % 4 != 0 || num_timesteps <= 0 || !t || !sqrt_ac || !sqrt_one_minus_ac || !rowvec_ok(x0, ldx, D) ||
+        !rowvec_ok(out, ldo, D) || (noise && !rowvec_ok(noise, ldn, D)) || (noise_out && !rowvec_ok(noise_out, ldno, D)))
+        return fail(ADCDIFF_E_BADARG, "q_sample: B=%d D=%d (multiple of 4), pointers 16-byte aligned, ld >= D", B, D);
+    const long total4 = (long)B * (D / 4);
+    const dim3 grid((unsigned)((total4 + 255) / 256));
+    if (noise)
+        hipLaunchKernelGGL((q_sample_kernel<true>), grid, dim3(256), 0, as_stream(stream), x0, ldx, t, sqrt_ac, sqrt_one_minus_ac,
+                           noise, ldn, out, ldo, noise_out, ldno, total4, D / 4, seed, step, row_offset);
+    else
+        hipLaunchKernelGGL((q_sample_kernel<false>), grid, dim3(256), 0, as_stream(stream), x0, ldx, t, sqrt_ac, sqrt_one_minus_ac,
+                           noise, ldn, out, ldo, noise_out, ldno, total4, D / 4, seed, step, row_offset);
+    return check_launch("q_sample");
+}

@@ -1,0 +1,427 @@
+// Host-side plan of the denoiser (UNetModel.forward, diffusion_model.py:749-789) and of the reverse
+// loops over the kernels of gemm.hip / elementwise.hip.  Nothing here allocates device memory: packed
+// weights and timestep tables live in the caller's arena, activations in the caller's workspace, both
+// carved by a bump allocator whose dry run gives the sizes reported to the caller.
+//
+// Per ResidualBlock (diffusion_model.py:875-907), with the input given as one or two parts (the
+// decoder's cat([h, skip]) is never materialised un-normalised):
+//   a1 = SiLU(GroupNorm1(parts))                     groupnorm_silu per part (groups never straddle parts)
+//   h1 = [a1 | s] * [W1 | Wtp]^T + b1 (+ table[t])   one GEMM; the time_proj term is a per-timestep table
+//                                                    row when unconditional, an extra K segment
+//                                                    s = SiLU(t_emb + c_emb) when a condition is given
+//   a2 = SiLU(GroupNorm2(h1))
+//   o  = [a2 | parts] * [W2 | Wres]^T + b2 + bres    one GEMM (Identity residual: + x in the epilogue)
+#include <cstring>
+#include <new>
+
+#include "common.h"
+
+namespace adcdiff {
+
+int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream);
+int groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const float* gamma, const float* beta, float eps,
+                   int out_dtype, void* out, int ldo, void* raw_out, int ldraw, hipStream_t stream);
+int sinusoid_table(float* out, int ld, int rows, int half, const float* freq, hipStream_t stream);
+int temb_silu(const float* te_table, int ldt, const int64_t* t_rows, int t_uniform, const float* cemb, int ldce, int dtype,
+              void* out, int ldo, int rows, int H, hipStream_t stream);
+int cast_pack(const float* src, int lds_, int dtype, void* dst, int ldd, int col0, int rows, int cols, hipStream_t stream);
+int add_vec(const float* a, const float* b, float* out, int n, hipStream_t stream);
+
+static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int num_groups(int dim) {   // diffusion_model.py:723-730, 840-847
+    if (dim < 4) return 1;
+    for (int g = dim < 32 ? dim : 32; g > 0; --g)
+        if (dim % g == 0) return g;
+    return 1;
+}
+
+struct Bump {
+    char* base;
+    size_t off = 0, cap;
+    Bump(void* b, size_t c) : base(reinterpret_cast<char*>(b)), cap(c) {}
+    void* take(size_t bytes) {
+        void* p = base + off;   // in a dry run base is null and only `off` matters
+        off += round_up(bytes, 256);
+        return p;
+    }
+};
+
+struct BlockPlan {
+    int cin, cout, nparts, part_c[2];
+    bool has_res;
+    int g1, g2, tb_off, ldw1, ldw2;
+    void *w1cat, *w2cat;
+    float *bias1, *bias1_cond, *bias2;
+};
+
+}  // namespace adcdiff
+
+using namespace adcdiff;
+
+struct adcdiff_unet {
+    adcdiff_unet_params prm;
+    int dtype, esz, D, H, O, T, Tp, sumN;
+    BlockPlan blk[10];
+    float *sin_table, *te_hidden, *te_table, *s_table, *wtp_all, *btp_all, *tb_table;
+    void *w_out, *w_c0, *w_c2;
+    size_t arena_used;
+    bool packed;
+};
+
+static int plan_dims(adcdiff_unet* n, int input_dim, int hidden_dim, int output_dim, int num_timesteps, int dtype) {
+    if (dtype != ADCDIFF_F32 && dtype != ADCDIFF_BF16) return fail(ADCDIFF_E_BADARG, "unet: unknown dtype %d", dtype);
+    if (input_dim <= 0 || hidden_dim <= 0 || output_dim <= 0 || input_dim % 64 || hidden_dim % 64 || output_dim % 64)
+        return fail(ADCDIFF_E_BADARG, "unet: input_dim=%d hidden_dim=%d output_dim=%d must be positive multiples of 64", input_dim,
+                    hidden_dim, output_dim);
+    if (num_timesteps <= 0) return fail(ADCDIFF_E_BADARG, "unet: num_timesteps=%d", num_timesteps);
+    n->dtype = dtype; n->esz = dtype == ADCDIFF_BF16 ? 2 : 4;
+    n->D = input_dim; n->H = hidden_dim; n->O = output_dim; n->T = num_timesteps;
+    n->Tp = (int)round_up((size_t)num_timesteps, 128);
+    const int h = hidden_dim;
+    const int cin[10] = {input_dim, h, 2 * h, 4 * h, 8 * h, 8 * h, 16 * h, 8 * h, 4 * h, 2 * h};
+    const int cout[10] = {h, 2 * h, 4 * h, 8 * h, 8 * h, 8 * h, 4 * h, 2 * h, h, h};
+    int off = 0;
+    for (int i = 0; i < 10; ++i) {
+        BlockPlan& b = n->blk[i];
+        b.cin = cin[i]; b.cout = cout[i]; b.has_res = cin[i] != cout[i];
+        b.nparts = i >= 6 ? 2 : 1;
+        b.part_c[0] = i >= 6 ? cin[i] / 2 : cin[i];
+        b.part_c[1] = i >= 6 ? cin[i] / 2 : 0;
+        b.g1 = num_groups(b.cin); b.g2 = num_groups(b.cout);
+        const int gs = b.cin / b.g1;
+        if (b.nparts == 2 && b.part_c[0] % gs != 0)
+            return fail(ADCDIFF_E_BADARG, "unet: GroupNorm groups of %d channels straddle the skip concatenation at width %d", gs, b.cin);
+        b.tb_off = off; off += b.cout;
+        b.ldw1 = b.cin + h;
+        b.ldw2 = b.cout + (b.has_res ? b.cin : 0);
+    }
+    n->sumN = off;
+    return ADCDIFF_OK;
+}
+
+// Carve the arena; with a null base this is the size computation.
+static void carve_arena(adcdiff_unet* n, void* arena, size_t cap) {
+    Bump a(arena, cap);
+    const size_t e = (size_t)n->esz;
+    for (int i = 0; i < 10; ++i) {
+        BlockPlan& b = n->blk[i];
+        b.w1cat = a.take((size_t)b.cout * b.ldw1 * e);
+        b.w2cat = a.take((size_t)b.cout * b.ldw2 * e);
+        b.bias1 = (float*)a.take((size_t)b.cout * 4);
+        b.bias1_cond = (float*)a.take((size_t)b.cout * 4);
+        b.bias2 = (float*)a.take((size_t)b.cout * 4);
+    }
+    n->w_out = a.take((size_t)n->O * n->H * e);
+    n->w_c0 = a.take((size_t)n->H * n->D * e);
+    n->w_c2 = a.take((size_t)n->H * n->H * e);
+    n->sin_table = (float*)a.take((size_t)n->Tp * n->H * 4);
+    n->te_hidden = (float*)a.take((size_t)n->Tp * 4 * n->H * 4);
+    n->te_table = (float*)a.take((size_t)n->Tp * n->H * 4);
+    n->s_table = (float*)a.take((size_t)n->Tp * n->H * 4);
+    n->wtp_all = (float*)a.take((size_t)n->sumN * n->H * 4);
+    n->btp_all = (float*)a.take((size_t)n->sumN * 4);
+    n->tb_table = (float*)a.take((size_t)n->Tp * n->sumN * 4);
+    n->arena_used = a.off;
+}
+
+extern "C" size_t adcdiff_unet_arena_bytes(int input_dim, int hidden_dim, int output_dim, int num_timesteps, int dtype) {
+    adcdiff_unet n{};
+    if (plan_dims(&n, input_dim, hidden_dim, output_dim, num_timesteps, dtype) != ADCDIFF_OK) return 0;
+    carve_arena(&n, nullptr, 0);
+    return n.arena_used;
+}
+
+extern "C" int adcdiff_unet_create(const adcdiff_unet_params* p, int dtype, void* arena, size_t arena_bytes, adcdiff_unet** out) {
+    if (!p || !arena || !out) return fail(ADCDIFF_E_BADARG, "unet_create: null argument");
+    adcdiff_unet* n = new (std::nothrow) adcdiff_unet{};
+    if (!n) return fail(ADCDIFF_E_BADARG, "unet_create: out of host memory");
+    int rc = plan_dims(n, p->input_dim, p->hidden_dim, p->output_dim, p->num_timesteps, dtype);
+    if (rc != ADCDIFF_OK) { delete n; return rc; }
+    if (p->input_dim != p->output_dim) {
+        // the reverse loop feeds the [B, output_dim] latent back as the [B, input_dim] input (diffusion_model.py:299, 702)
+        delete n;
+        return fail(ADCDIFF_E_BADARG, "unet_create: input_dim=%d != output_dim=%d cannot be sampled", p->input_dim, p->output_dim);
+    }
+    n->prm = *p;
+    if (!aligned16(arena)) { delete n; return fail(ADCDIFF_E_BADARG, "unet_create: arena must be 16-byte aligned"); }
+    carve_arena(n, arena, arena_bytes);
+    if (n->arena_used > arena_bytes) {
+        const size_t need = n->arena_used;
+        delete n;
+        return fail(ADCDIFF_E_WORKSPACE, "unet_create: arena of %zu bytes, %zu needed", arena_bytes, need);
+    }
+    const float* req[] = {p->time_lin1_w, p->time_lin1_b, p->time_lin2_w, p->time_lin2_b, p->cond0_w, p->cond0_b, p->cond2_w,
+                          p->cond2_b, p->out_norm_w, p->out_norm_b, p->out_w, p->out_b, p->sinusoid_freq};
+    for (const float* q : req)
+        if (!q || !aligned16(q)) { delete n; return fail(ADCDIFF_E_BADARG, "unet_create: null or misaligned parameter pointer"); }
+    for (int i = 0; i < 10; ++i) {
+        const adcdiff_block_params& b = p->blocks[i];
+        const float* rb[] = {b.norm1_w, b.norm1_b, b.norm2_w, b.norm2_b, b.linear1_w, b.linear1_b, b.linear2_w, b.linear2_b,
+                             b.time_proj_w, b.time_proj_b};
+        for (const float* q : rb)
+            if (!q || !aligned16(q)) { delete n; return fail(ADCDIFF_E_BADARG, "unet_create: block %d: null or misaligned parameter", i); }
+        if (n->blk[i].has_res != (b.residual_w != nullptr) || (b.residual_w && !b.residual_b)) {
+            delete n;
+            return fail(ADCDIFF_E_BADARG, "unet_create: block %d: residual_proj presence does not match its dimensions", i);
+        }
+    }
+    n->packed = false;
+    *out = n;
+    return ADCDIFF_OK;
+}
+
+extern "C" void adcdiff_unet_destroy(adcdiff_unet* n) { delete n; }
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != ADCDIFF_OK) return rc_; } while (0)
+
+static adcdiff_gemm_args gemm_args(int dtype, int M, int m_valid, int N) {
+    adcdiff_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.dtype = dtype; g.M = M; g.m_valid = m_valid; g.N = N;
+    return g;
+}
+
+extern "C" int adcdiff_unet_pack(adcdiff_unet* n, void* workspace, size_t workspace_bytes, adcdiff_stream_t stream_) {
+    (void)workspace; (void)workspace_bytes;
+    if (!n) return fail(ADCDIFF_E_BADARG, "unet_pack: null plan");
+    hipStream_t st = as_stream(stream_);
+    const adcdiff_unet_params& p = n->prm;
+    const int H = n->H;
+    for (int i = 0; i < 10; ++i) {
+        const BlockPlan& b = n->blk[i];
+        const adcdiff_block_params& q = p.blocks[i];
+        TRY(cast_pack(q.linear1_w, b.cin, n->dtype, b.w1cat, b.ldw1, 0, b.cout, b.cin, st));
+        TRY(cast_pack(q.time_proj_w, H, n->dtype, b.w1cat, b.ldw1, b.cin, b.cout, H, st));
+        TRY(cast_pack(q.linear2_w, b.cout, n->dtype, b.w2cat, b.ldw2, 0, b.cout, b.cout, st));
+        if (b.has_res) TRY(cast_pack(q.residual_w, b.cin, n->dtype, b.w2cat, b.ldw2, b.cout, b.cout, b.cin, st));
+        TRY(add_vec(q.linear1_b, nullptr, b.bias1, b.cout, st));
+        TRY(add_vec(q.linear1_b, q.time_proj_b, b.bias1_cond, b.cout, st));
+        TRY(add_vec(q.linear2_b, b.has_res ? q.residual_b : nullptr, b.bias2, b.cout, st));
+        TRY(cast_pack(q.time_proj_w, H, ADCDIFF_F32, n->wtp_all + (size_t)b.tb_off * H, H, 0, b.cout, H, st));
+        TRY(add_vec(q.time_proj_b, nullptr, n->btp_all + b.tb_off, b.cout, st));
+    }
+    TRY(cast_pack(p.out_w, H, n->dtype, n->w_out, H, 0, n->O, H, st));
+    TRY(cast_pack(p.cond0_w, n->D, n->dtype, n->w_c0, n->D, 0, H, n->D, st));
+    TRY(cast_pack(p.cond2_w, H, n->dtype, n->w_c2, H, 0, H, H, st));
+
+    // TimeEmbedding(t) for every timestep (diffusion_model.py:802-823), float32 throughout
+    TRY(sinusoid_table(n->sin_table, H, n->Tp, H / 2, p.sinusoid_freq, st));
+    adcdiff_gemm_args g = gemm_args(ADCDIFF_F32, n->Tp, 0, 4 * H);
+    g.nseg = 1; g.A[0] = n->sin_table; g.lda[0] = H; g.K[0] = H; g.W = p.time_lin1_w; g.ldw = H; g.bias = p.time_lin1_b;
+    g.act = 1; g.out_f32 = n->te_hidden; g.ldo_f32 = 4 * H;
+    TRY(gemm_dispatch(g, st));
+    g = gemm_args(ADCDIFF_F32, n->Tp, 0, H);
+    g.nseg = 1; g.A[0] = n->te_hidden; g.lda[0] = 4 * H; g.K[0] = 4 * H; g.W = p.time_lin2_w; g.ldw = 4 * H; g.bias = p.time_lin2_b;
+    g.out_f32 = n->te_table; g.ldo_f32 = H;
+    TRY(gemm_dispatch(g, st));
+    // every block's time_proj(SiLU(t_emb)) for every timestep (diffusion_model.py:859-862, 893)
+    TRY(temb_silu(n->te_table, H, nullptr, -1, nullptr, 0, ADCDIFF_F32, n->s_table, H, n->Tp, H, st));
+    g = gemm_args(ADCDIFF_F32, n->Tp, 0, n->sumN);
+    g.nseg = 1; g.A[0] = n->s_table; g.lda[0] = H; g.K[0] = H; g.W = n->wtp_all; g.ldw = H; g.bias = n->btp_all;
+    g.out_f32 = n->tb_table; g.ldo_f32 = n->sumN;
+    TRY(gemm_dispatch(g, st));
+    n->packed = true;
+    return ADCDIFF_OK;
+}
+
+namespace {
+
+struct Part {
+    const float* f32;   // [rows, C] float32 activations (leading dimension ld)
+    int C, ld;
+    const void* raw;    // the same values in the GEMM operand type with padded rows, or null if not made yet
+};
+
+// One denoiser forward.  With dry = true nothing is launched and only the bump offset advances.
+int forward_impl(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform, const float* cemb,
+                 int ldce, float* eps, int lde, Bump& ws, bool dry, hipStream_t st) {
+    const int Bp = (int)round_up((size_t)B, 128);
+    const size_t e = (size_t)n->esz;
+    const int H = n->H, dt = n->dtype;
+    const adcdiff_unet_params& p = n->prm;
+    const bool cond = cemb != nullptr;
+
+    const void* s_op = nullptr;
+    if (cond || dry) {   // the dry run sizes for the conditional case, the larger one
+        void* s = ws.take((size_t)Bp * H * e);
+        if (!dry) TRY(temb_silu(n->te_table, H, t_rows, t_uniform, cemb, ldce, dt, s, H, B, H, st));
+        s_op = s;
+    }
+
+    Part outs[10];
+    Part cur[2];
+    cur[0] = Part{x, n->D, ldx, nullptr};
+    int ncur = 1;
+    for (int i = 0; i < 10; ++i) {
+        const BlockPlan& b = n->blk[i];
+        const adcdiff_block_params& q = p.blocks[i];
+        if (i >= 6) {   // decoder input = cat([h, skip]) with skip = encoder output 3, 2, 1, 0 (diffusion_model.py:781-782)
+            cur[1] = outs[9 - i];
+            ncur = 2;
+        }
+        // a1 = SiLU(GroupNorm1(input)), written as one [Bp, cin] operand
+        char* a1 = (char*)ws.take((size_t)Bp * b.cin * e);
+        const int gs = b.cin / b.g1;
+        int col = 0;
+        for (int k = 0; k < ncur; ++k) {
+            void* raw = nullptr;
+            if (b.has_res && !cur[k].raw) raw = ws.take((size_t)Bp * cur[k].C * e);
+            if (!dry)
+                TRY(groupnorm_silu(cur[k].f32, cur[k].ld, B, cur[k].C, cur[k].C / gs, q.norm1_w + col, q.norm1_b + col, 1e-5f, dt,
+                                   a1 + (size_t)col * e, b.cin, raw, cur[k].C, st));
+            if (raw) cur[k].raw = raw;
+            col += cur[k].C;
+        }
+        // h1 = linear1(a1) + time_proj(SiLU(t_emb))
+        float* h1 = (float*)ws.take((size_t)Bp * b.cout * 4);
+        if (!dry) {
+            adcdiff_gemm_args g = gemm_args(dt, Bp, B, b.cout);
+            g.nseg = 1; g.A[0] = a1; g.lda[0] = b.cin; g.K[0] = b.cin;
+            g.W = b.w1cat; g.ldw = b.ldw1;
+            if (cond) {
+                g.nseg = 2; g.A[1] = s_op; g.lda[1] = H; g.K[1] = H;
+                g.bias = b.bias1_cond;
+            } else {
+                g.bias = b.bias1;
+                if (t_rows) { g.rowbias = n->tb_table + b.tb_off; g.ldrb = n->sumN; g.rowbias_idx = t_rows; }
+                else { g.rowbias = n->tb_table + (size_t)t_uniform * n->sumN + b.tb_off; g.ldrb = 0; }
+            }
+            g.out_f32 = h1; g.ldo_f32 = b.cout;
+            TRY(gemm_dispatch(g, st));
+        }
+        // a2 = SiLU(GroupNorm2(h1)); dropout is the identity in eval mode (diffusion_model.py:896-898)
+        void* a2 = ws.take((size_t)Bp * b.cout * e);
+        if (!dry) TRY(groupnorm_silu(h1, b.cout, B, b.cout, b.g2, q.norm2_w, q.norm2_b, 1e-5f, dt, a2, b.cout, nullptr, 0, st));
+        // o = linear2(a2) + residual_proj(input)
+        float* o = (float*)ws.take((size_t)Bp * b.cout * 4);
+        if (!dry) {
+            adcdiff_gemm_args g = gemm_args(dt, Bp, B, b.cout);
+            g.nseg = 1; g.A[0] = a2; g.lda[0] = b.cout; g.K[0] = b.cout;
+            g.W = b.w2cat; g.ldw = b.ldw2; g.bias = b.bias2;
+            if (b.has_res) {
+                for (int k = 0; k < ncur; ++k) {
+                    g.A[g.nseg] = cur[k].raw; g.lda[g.nseg] = cur[k].C; g.K[g.nseg] = cur[k].C;
+                    ++g.nseg;
+                }
+            } else {
+                g.residual = cur[0].f32; g.ldr = cur[0].ld;
+            }
+            g.out_f32 = o; g.ldo_f32 = b.cout;
+            TRY(gemm_dispatch(g, st));
+        }
+        // in float32 the block output is its own GEMM operand (padded rows included)
+        outs[i] = Part{o, b.cout, b.cout, dt == ADCDIFF_F32 ? (const void*)o : nullptr};
+        if (i >= 1 && i <= 4 && cur[0].raw) outs[i - 1].raw = cur[0].raw;   // keep the converted copy of a skip tensor
+        cur[0] = outs[i];
+        ncur = 1;
+    }
+    // output head: Linear(SiLU(GroupNorm(h))) (diffusion_model.py:786-788)
+    void* a = ws.take((size_t)Bp * H * e);
+    if (!dry) {
+        TRY(groupnorm_silu(cur[0].f32, cur[0].ld, B, H, num_groups(H), p.out_norm_w, p.out_norm_b, 1e-5f, dt, a, H, nullptr, 0, st));
+        adcdiff_gemm_args g = gemm_args(dt, Bp, B, n->O);
+        g.nseg = 1; g.A[0] = a; g.lda[0] = H; g.K[0] = H; g.W = n->w_out; g.ldw = H; g.bias = p.out_b;
+        g.out_f32 = eps; g.ldo_f32 = lde;
+        TRY(gemm_dispatch(g, st));
+    }
+    return ADCDIFF_OK;
+}
+
+size_t forward_bytes(adcdiff_unet* n, int B) {
+    Bump ws(nullptr, 0);
+    forward_impl(n, nullptr, 0, B, nullptr, 0, nullptr, 0, nullptr, 0, ws, true, nullptr);
+    // + the eps buffer of the sampling loops and the operand copy of the condition
+    const size_t Bp = round_up((size_t)B, 128);
+    return ws.off + round_up(Bp * n->O * 4, 256) + round_up(Bp * n->D * n->esz, 256) + round_up(Bp * n->H * n->esz, 256);
+}
+
+int check_forward_args(adcdiff_unet* n, const char* who, int B, const void* ws, size_t ws_bytes) {
+    if (!n) return fail(ADCDIFF_E_BADARG, "%s: null plan", who);
+    if (!n->packed) return fail(ADCDIFF_E_BADARG, "%s: adcdiff_unet_pack has not been called", who);
+    if (B <= 0) return fail(ADCDIFF_E_BADARG, "%s: batch %d", who, B);
+    if (!ws || !aligned16(ws)) return fail(ADCDIFF_E_BADARG, "%s: workspace null or misaligned", who);
+    const size_t need = forward_bytes(n, B);
+    if (ws_bytes < need) return fail(ADCDIFF_E_WORKSPACE, "%s: workspace of %zu bytes, %zu needed for batch %d", who, ws_bytes, need, B);
+    return ADCDIFF_OK;
+}
+
+}  // namespace
+
+extern "C" size_t adcdiff_unet_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int dtype, int batch) {
+    adcdiff_unet n{};
+    if (batch <= 0 || plan_dims(&n, input_dim, hidden_dim, output_dim, 1, dtype) != ADCDIFF_OK) return 0;
+    return forward_bytes(&n, batch);
+}
+
+extern "C" int adcdiff_unet_condition_embed(adcdiff_unet* n, const float* cond, int ldc, int B, float* cemb, int ldce,
+                                            void* workspace, size_t workspace_bytes, adcdiff_stream_t stream_) {
+    TRY(check_forward_args(n, "unet_condition_embed", B, workspace, workspace_bytes));
+    if (!cond || !cemb || ldc < n->D || ldce < n->H) return fail(ADCDIFF_E_BADARG, "unet_condition_embed: bad cond / cemb arguments");
+    hipStream_t st = as_stream(stream_);
+    const int Bp = (int)round_up((size_t)B, 128);
+    Bump ws(workspace, workspace_bytes);
+    void* c_op = ws.take((size_t)Bp * n->D * n->esz);
+    void* hid = ws.take((size_t)Bp * n->H * n->esz);
+    TRY(cast_pack(cond, ldc, n->dtype, c_op, n->D, 0, B, n->D, st));
+    adcdiff_gemm_args g = gemm_args(n->dtype, Bp, B, n->H);
+    g.nseg = 1; g.A[0] = c_op; g.lda[0] = n->D; g.K[0] = n->D; g.W = n->w_c0; g.ldw = n->D; g.bias = n->prm.cond0_b; g.act = 1;
+    if (n->dtype == ADCDIFF_BF16) { g.out_bf16 = hid; g.ldo_bf16 = n->H; } else { g.out_f32 = (float*)hid; g.ldo_f32 = n->H; }
+    TRY(gemm_dispatch(g, st));
+    g = gemm_args(n->dtype, Bp, B, n->H);
+    g.nseg = 1; g.A[0] = hid; g.lda[0] = n->H; g.K[0] = n->H; g.W = n->w_c2; g.ldw = n->H; g.bias = n->prm.cond2_b;
+    g.out_f32 = cemb; g.ldo_f32 = ldce;
+    return gemm_dispatch(g, st);
+}
+
+extern "C" int adcdiff_unet_forward(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform,
+                                    const float* cemb, int ldce, float* eps, int lde, void* workspace, size_t workspace_bytes,
+                                    adcdiff_stream_t stream_) {
+    TRY(check_forward_args(n, "unet_forward", B, workspace, workspace_bytes));
+    if (!x || !eps || ldx < n->D || lde < n->O || !aligned16(x) || !aligned16(eps) || ldx % 4 || lde % 4)
+        return fail(ADCDIFF_E_BADARG, "unet_forward: x / eps null, misaligned or leading dimension too small");
+    if (!t_rows && (t_uniform < 0 || t_uniform >= n->T)) return fail(ADCDIFF_E_BADARG, "unet_forward: timestep %d outside 0..%d", t_uniform, n->T - 1);
+    if (cemb && (ldce < n->H || !aligned16(cemb))) return fail(ADCDIFF_E_BADARG, "unet_forward: bad condition embedding");
+    Bump ws(workspace, workspace_bytes);
+    return forward_impl(n, x, ldx, B, t_rows, t_uniform, cemb, ldce, eps, lde, ws, false, as_stream(stream_));
+}
+
+extern "C" int adcdiff_ddpm_sample_loop(adcdiff_unet* n, float* x, int ldx, int B, const float* cemb, int ldce,
+                                        const adcdiff_ddpm_coef* coef, int t_start, int t_stop, const float* noise,
+                                        long long noise_step_stride, uint64_t seed, uint64_t row_offset, void* workspace,
+                                        size_t workspace_bytes, adcdiff_stream_t stream_) {
+    TRY(check_forward_args(n, "ddpm_sample_loop", B, workspace, workspace_bytes));
+    if (!x || !coef || ldx < n->D || !aligned16(x) || ldx % 4) return fail(ADCDIFF_E_BADARG, "ddpm_sample_loop: bad x / coef");
+    if (t_start >= n->T || t_stop < 0 || t_stop > t_start) return fail(ADCDIFF_E_BADARG, "ddpm_sample_loop: steps %d..%d outside 0..%d", t_start, t_stop, n->T - 1);
+    if (cemb && (ldce < n->H || !aligned16(cemb))) return fail(ADCDIFF_E_BADARG, "ddpm_sample_loop: bad condition embedding");
+    const int Bp = (int)round_up((size_t)B, 128);
+    for (int t = t_start; t >= t_stop; --t) {
+        Bump ws(workspace, workspace_bytes);
+        float* eps = (float*)ws.take((size_t)Bp * n->O * 4);
+        TRY(forward_impl(n, x, ldx, B, nullptr, t, cemb, ldce, eps, n->O, ws, false, as_stream(stream_)));
+        const float* nz = noise ? noise + (size_t)(t_start - t) * (size_t)noise_step_stride : nullptr;
+        TRY(adcdiff_ddpm_step(x, ldx, eps, n->O, nz, n->O, x, ldx, B, n->O, coef[t], seed, (uint32_t)t, row_offset, stream_));
+    }
+    return ADCDIFF_OK;
+}
+
+extern "C" int adcdiff_ddim_sample_loop(adcdiff_unet* n, float* x, int ldx, int B, const float* cemb, int ldce, const int* timesteps,
+                                        const adcdiff_ddim_coef* coef, int nsteps, const float* noise, long long noise_step_stride,
+                                        uint64_t seed, uint64_t row_offset, void* workspace, size_t workspace_bytes,
+                                        adcdiff_stream_t stream_) {
+    TRY(check_forward_args(n, "ddim_sample_loop", B, workspace, workspace_bytes));
+    if (!x || !coef || !timesteps || nsteps <= 0 || ldx < n->D || !aligned16(x) || ldx % 4)
+        return fail(ADCDIFF_E_BADARG, "ddim_sample_loop: bad x / coef / timesteps");
+    if (cemb && (ldce < n->H || !aligned16(cemb))) return fail(ADCDIFF_E_BADARG, "ddim_sample_loop: bad condition embedding");
+    const int Bp = (int)round_up((size_t)B, 128);
+    for (int i = 0; i < nsteps; ++i) {
+        const int t = timesteps[i];
+        if (t < 0 || t >= n->T) return fail(ADCDIFF_E_BADARG, "ddim_sample_loop: timestep %d outside 0..%d", t, n->T - 1);
+        Bump ws(workspace, workspace_bytes);
+        float* eps = (float*)ws.take((size_t)Bp * n->O * 4);
+        TRY(forward_impl(n, x, ldx, B, nullptr, t, cemb, ldce, eps, n->O, ws, false, as_stream(stream_)));
+        const float* nz = noise ? noise + (size_t)i * (size_t)noise_step_stride : nullptr;
+        TRY(adcdiff_ddim_step(x, ldx, eps, n->O, nz, n->O, x, ldx, B, n->O, coef[i], seed, (uint32_t)t, row_offset, stream_));
+    }
+    return ADCDIFF_OK;
+}

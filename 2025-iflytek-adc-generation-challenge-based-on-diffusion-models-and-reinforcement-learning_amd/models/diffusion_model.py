@@ -1,0 +1,612 @@
+"""Drop-in mirror of the reference's ``src/models/diffusion_model.py`` class surface on MI355X.
+
+Same constructor dict, attribute names, method names and ``state_dict`` keys as the reference
+(``DiffusionModel`` diffusion_model.py:24-107, ``UNetModel`` :677-747, ``TimeEmbedding`` :792-800,
+``ResidualBlock`` :826-873); the arithmetic is done by libadcdiff.so (hand-written gfx950 kernels
+behind include/adcdiff.h).  The modules below hold the parameters under the reference's names; their
+``forward`` methods call the HIP library and raise if the tensors are not on the GPU -- there is no
+PyTorch or CPU implementation of the path in this package.
+
+Deliberate differences from the reference, all of them places where the reference cannot run:
+* ``_extract`` gathers on the tensor's own device (the reference indexes a device table with a CPU
+  index, :505-507, which raises on a GPU);
+* batches larger than ``max_batch_size`` are sampled in one piece (the reference's chunk path reads a
+  non-existent attribute, :277); ``max_batch_size`` is kept as an attribute only;
+* noise comes from a counter RNG (Philox4x32-10 keyed by seed, global row, timestep) instead of
+  torch's global generator, so a batch sharded over GPUs draws the same noise as the unsharded one;
+  the seed of each call is drawn from torch's CPU generator, so ``torch.manual_seed`` still makes
+  runs reproducible;
+* sampling runs the denoiser in eval mode (dropout off): the reference never calls ``.eval()`` and
+  therefore samples with dropout active, which no parity test could pin.
+"""
+import ctypes as C
+import gc
+import logging
+import math
+from typing import Dict, Optional, Tuple
+
+import psutil
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.optim import Adam, AdamW
+from torch.optim.lr_scheduler import CosineAnnealingLR, OneCycleLR
+
+from .. import _lib, ops
+from .._lib import AdcdiffError, check
+
+
+def get_num_groups(dim):
+    """Largest divisor of dim that is <= 32 (diffusion_model.py:723-730, 840-847)."""
+    if dim < 4:
+        return 1
+    for num_groups in range(min(32, dim), 0, -1):
+        if dim % num_groups == 0:
+            return num_groups
+    return 1
+
+
+def _seed_from_torch():
+    """A 62-bit seed drawn from torch's CPU generator (so torch.manual_seed controls sampling)."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+class TimeEmbedding(nn.Module):
+    """Parameters of the reference's TimeEmbedding (diffusion_model.py:792-823)."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.dim = dim
+        self.linear1 = nn.Linear(dim, dim * 4)
+        self.linear2 = nn.Linear(dim * 4, dim)
+
+    def frequencies(self):
+        """exp(arange(half) * -(ln 1e4 / (half - 1))) computed with the reference's own expression on
+        the CPU (:812-814), so the table is the one the reference gets on the same host."""
+        half_dim = self.dim // 2
+        emb = math.log(10000) / (half_dim - 1)
+        return torch.exp(torch.arange(half_dim) * -emb)
+
+    def forward(self, t: torch.Tensor) -> torch.Tensor:
+        ops._need_gpu(t)
+        freq = self.frequencies().to(t.device)
+        arg = t[:, None] * freq[None, :]
+        # the sinusoid of a handful of rows; the sampling path uses the library's per-timestep table instead
+        emb = torch.cat([torch.sin(arg), torch.cos(arg)], dim=-1)
+        emb = ops.linear(emb, self.linear1.weight, self.linear1.bias, act=1)
+        return ops.linear(emb, self.linear2.weight, self.linear2.bias)
+
+
+class ResidualBlock(nn.Module):
+    """Parameters of the reference's ResidualBlock (diffusion_model.py:826-873); attention is dead code
+    in the reference (never enabled, :702-719) and is not built."""
+
+    def __init__(self, in_dim: int, out_dim: int, time_emb_dim: int = None, use_attention: bool = False,
+                 dropout: float = 0.1):
+        super().__init__()
+        if use_attention:
+            raise NotImplementedError("use_attention is never enabled by the reference and is not built")
+        if time_emb_dim is None:
+            time_emb_dim = out_dim
+        if in_dim < 4 or out_dim < 4:
+            raise ValueError("widths below 4 use LayerNorm in the reference and are not supported")
+        self.use_attention = False
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.norm1 = nn.GroupNorm(get_num_groups(in_dim), in_dim)
+        self.norm2 = nn.GroupNorm(get_num_groups(out_dim), out_dim)
+        self.linear1 = nn.Linear(in_dim, out_dim)
+        self.linear2 = nn.Linear(out_dim, out_dim)
+        self.dropout = nn.Dropout(dropout)   # identity in the sampling path
+        self.time_proj = nn.Sequential(nn.SiLU(), nn.Linear(time_emb_dim, out_dim))
+        self.residual_proj = nn.Linear(in_dim, out_dim) if in_dim != out_dim else nn.Identity()
+
+    def forward(self, x: torch.Tensor, t_emb: torch.Tensor) -> torch.Tensor:
+        """Eval-mode forward of one block through the single-kernel entry points (float32 operands)."""
+        ops._need_gpu(x, t_emb)
+        B = x.shape[0]
+        P = ops._pad_rows(B)
+        a1 = torch.zeros((P, self.in_dim), device=x.device)
+        a1[:B] = ops.groupnorm_silu(x.contiguous(), self.norm1.num_groups, self.norm1.weight.detach(), self.norm1.bias.detach())
+        s = torch.zeros((P, t_emb.shape[1]), device=x.device)
+        s[:B] = t_emb / (1.0 + torch.exp(-t_emb))
+        w1 = torch.cat([self.linear1.weight.detach(), self.time_proj[1].weight.detach()], dim=1).contiguous()
+        h = ops.gemm([a1, s], w1, bias=(self.linear1.bias + self.time_proj[1].bias).detach(), m_valid=B)
+        a2 = torch.zeros((P, self.out_dim), device=x.device)
+        a2[:B] = ops.groupnorm_silu(h[:B], self.norm2.num_groups, self.norm2.weight.detach(), self.norm2.bias.detach())
+        if isinstance(self.residual_proj, nn.Identity):
+            out = ops.gemm([a2], self.linear2.weight.detach().contiguous(), bias=self.linear2.bias.detach(),
+                           residual=x.contiguous(), m_valid=B)
+        else:
+            xr = torch.zeros((P, self.in_dim), device=x.device)
+            xr[:B] = x
+            w2 = torch.cat([self.linear2.weight.detach(), self.residual_proj.weight.detach()], dim=1).contiguous()
+            out = ops.gemm([a2, xr], w2, bias=(self.linear2.bias + self.residual_proj.bias).detach(), m_valid=B)
+        return out[:B]
+
+
+class _Engine:
+    """Owns the packed-weight arena, the workspace and the native plan of one UNetModel."""
+
+    def __init__(self, model, dtype_code):
+        self.lib = _lib.load()
+        self.model = model
+        self.dtype = dtype_code
+        self.handle = None
+        self.arena = None
+        self.workspace = None
+        self.key = None
+        self.version = None
+        self.freq = None
+
+    def _param_key(self):
+        return tuple(p.data_ptr() for p in self.model.parameters())
+
+    def _param_version(self):
+        return sum(p._version for p in self.model.parameters())
+
+    def destroy(self):
+        if self.handle is not None:
+            self.lib.adcdiff_unet_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def ensure(self, device):
+        m = self.model
+        key = self._param_key()
+        if self.handle is None or key != self.key:
+            self.destroy()
+            for p in m.parameters():
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise AdcdiffError("UNetModel parameters must be contiguous float32 tensors on the GPU "
+                                       "(found %s on %s); there is no CPU fallback" % (p.dtype, p.device))
+            self.freq = m.time_embed.frequencies().to(device=device, dtype=torch.float32).contiguous()
+            prm = _lib.UnetParams()
+            prm.input_dim, prm.hidden_dim, prm.output_dim, prm.num_timesteps = m.input_dim, m.hidden_dim, m.output_dim, m.num_timesteps
+            prm.time_lin1_w, prm.time_lin1_b = m.time_embed.linear1.weight.data_ptr(), m.time_embed.linear1.bias.data_ptr()
+            prm.time_lin2_w, prm.time_lin2_b = m.time_embed.linear2.weight.data_ptr(), m.time_embed.linear2.bias.data_ptr()
+            prm.cond0_w, prm.cond0_b = m.condition_embed[0].weight.data_ptr(), m.condition_embed[0].bias.data_ptr()
+            prm.cond2_w, prm.cond2_b = m.condition_embed[2].weight.data_ptr(), m.condition_embed[2].bias.data_ptr()
+            blocks = list(m.encoder) + list(m.middle) + list(m.decoder)
+            for i, b in enumerate(blocks):
+                bp = prm.blocks[i]
+                bp.norm1_w, bp.norm1_b = b.norm1.weight.data_ptr(), b.norm1.bias.data_ptr()
+                bp.norm2_w, bp.norm2_b = b.norm2.weight.data_ptr(), b.norm2.bias.data_ptr()
+                bp.linear1_w, bp.linear1_b = b.linear1.weight.data_ptr(), b.linear1.bias.data_ptr()
+                bp.linear2_w, bp.linear2_b = b.linear2.weight.data_ptr(), b.linear2.bias.data_ptr()
+                bp.time_proj_w, bp.time_proj_b = b.time_proj[1].weight.data_ptr(), b.time_proj[1].bias.data_ptr()
+                if isinstance(b.residual_proj, nn.Linear):
+                    bp.residual_w, bp.residual_b = b.residual_proj.weight.data_ptr(), b.residual_proj.bias.data_ptr()
+                else:
+                    bp.residual_w, bp.residual_b = None, None
+            prm.out_norm_w, prm.out_norm_b = m.output_norm.weight.data_ptr(), m.output_norm.bias.data_ptr()
+            prm.out_w, prm.out_b = m.output_layer.weight.data_ptr(), m.output_layer.bias.data_ptr()
+            prm.sinusoid_freq = self.freq.data_ptr()
+            nbytes = self.lib.adcdiff_unet_arena_bytes(m.input_dim, m.hidden_dim, m.output_dim, m.num_timesteps, self.dtype)
+            if nbytes == 0:
+                raise AdcdiffError("unsupported denoiser dimensions: %s" % self.lib.adcdiff_last_error().decode())
+            self.arena = torch.empty(nbytes, device=device, dtype=torch.uint8)
+            handle = C.c_void_p()
+            check(self.lib.adcdiff_unet_create(C.byref(prm), self.dtype, C.c_void_p(self.arena.data_ptr()), nbytes, C.byref(handle)))
+            self.handle, self.key, self.version = handle, key, None
+        version = self._param_version()
+        if version != self.version:
+            check(self.lib.adcdiff_unet_pack(self.handle, None, 0, ops._stream()))
+            self.version = version
+        return self.handle
+
+    def workspace_for(self, batch, device):
+        m = self.model
+        need = self.lib.adcdiff_unet_workspace_bytes(m.input_dim, m.hidden_dim, m.output_dim, self.dtype, batch)
+        if need == 0:
+            raise AdcdiffError(self.lib.adcdiff_last_error().decode())
+        if self.workspace is None or self.workspace.numel() < need or self.workspace.device != device:
+            self.workspace = None
+            self.workspace = torch.empty(need, device=device, dtype=torch.uint8)
+        return C.c_void_p(self.workspace.data_ptr()), self.workspace.numel()
+
+
+class UNetModel(nn.Module):
+    """The reference's MLP "U-Net" noise predictor (diffusion_model.py:677-789) on the HIP library."""
+
+    def __init__(self, input_dim: int, hidden_dim: int, output_dim: int, num_timesteps: int,
+                 enable_memory_efficient_attention: bool = True, compute_dtype: str = "bf16"):
+        super().__init__()
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+        self.output_dim = output_dim
+        self.num_timesteps = num_timesteps
+        self.enable_memory_efficient_attention = enable_memory_efficient_attention
+        self.compute_dtype = compute_dtype
+        if input_dim <= 0:
+            raise ValueError("input_dim must be positive")
+        self.time_embed = TimeEmbedding(hidden_dim)
+        self.condition_embed = nn.Sequential(nn.Linear(input_dim, hidden_dim), nn.SiLU(), nn.Linear(hidden_dim, hidden_dim))
+        self.encoder = nn.ModuleList([
+            ResidualBlock(input_dim, hidden_dim, hidden_dim),
+            ResidualBlock(hidden_dim, hidden_dim * 2, hidden_dim),
+            ResidualBlock(hidden_dim * 2, hidden_dim * 4, hidden_dim),
+            ResidualBlock(hidden_dim * 4, hidden_dim * 8, hidden_dim),
+        ])
+        self.middle = nn.ModuleList([
+            ResidualBlock(hidden_dim * 8, hidden_dim * 8, hidden_dim),
+            ResidualBlock(hidden_dim * 8, hidden_dim * 8, hidden_dim),
+        ])
+        self.decoder = nn.ModuleList([
+            ResidualBlock(hidden_dim * 16, hidden_dim * 4, hidden_dim),
+            ResidualBlock(hidden_dim * 8, hidden_dim * 2, hidden_dim),
+            ResidualBlock(hidden_dim * 4, hidden_dim, hidden_dim),
+            ResidualBlock(hidden_dim * 2, hidden_dim, hidden_dim),
+        ])
+        self.output_norm = nn.GroupNorm(get_num_groups(hidden_dim), hidden_dim)
+        self.output_layer = nn.Linear(hidden_dim, output_dim)
+        self._initialize_weights()
+        self._engines = {}
+
+    def _initialize_weights(self):
+        """xavier_uniform_ weights, zero biases, GroupNorm weight 1 / bias 0 (diffusion_model.py:738-747)."""
+        for module in self.modules():
+            if isinstance(module, nn.Linear):
+                nn.init.xavier_uniform_(module.weight)
+                if module.bias is not None:
+                    nn.init.zeros_(module.bias)
+            elif isinstance(module, nn.GroupNorm):
+                nn.init.ones_(module.weight)
+                nn.init.zeros_(module.bias)
+
+    # ---- native plumbing -------------------------------------------------------------------
+    def engine(self, compute_dtype=None):
+        code = ops.dtype_code(compute_dtype if compute_dtype is not None else self.compute_dtype)
+        if code not in self._engines:
+            self._engines[code] = _Engine(self, code)
+        return self._engines[code]
+
+    def _device(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise AdcdiffError("the denoiser runs on an MI355X only (parameters are on %s); no CPU fallback exists" % dev)
+        return dev
+
+    def condition_embedding(self, condition, compute_dtype=None):
+        """condition_embed(condition) (diffusion_model.py:694-698, 765): computed once per sampling call."""
+        dev = self._device()
+        eng = self.engine(compute_dtype)
+        handle = eng.ensure(dev)
+        cond = condition.to(device=dev, dtype=torch.float32).contiguous()
+        B = cond.shape[0]
+        ws, ws_bytes = eng.workspace_for(B, dev)
+        cemb = torch.empty((B, self.hidden_dim), device=dev, dtype=torch.float32)
+        check(eng.lib.adcdiff_unet_condition_embed(handle, ops._ptr(cond), cond.stride(0), B, ops._ptr(cemb), self.hidden_dim, ws,
+                                                   ws_bytes, ops._stream()))
+        return cemb
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Predicted noise for x [B, input_dim], per-row timesteps t [B] (diffusion_model.py:749-789)."""
+        dev = self._device()
+        ops._need_gpu(x, t, condition)
+        eng = self.engine()
+        handle = eng.ensure(dev)
+        x = x.to(torch.float32).contiguous()
+        t = t.to(torch.int64).contiguous()
+        B = x.shape[0]
+        if x.shape[1] != self.input_dim or t.shape[0] != B:
+            raise ValueError("x must be [B, %d] and t [B]" % self.input_dim)
+        cemb = self.condition_embedding(condition) if condition is not None else None
+        ws, ws_bytes = eng.workspace_for(B, dev)
+        eps = torch.empty((B, self.output_dim), device=dev, dtype=torch.float32)
+        check(eng.lib.adcdiff_unet_forward(handle, ops._ptr(x), x.stride(0), B, ops._ptr(t), 0, ops._ptr(cemb), self.hidden_dim,
+                                           ops._ptr(eps), self.output_dim, ws, ws_bytes, ops._stream()))
+        return eps
+
+
+class DiffusionModel(nn.Module):
+    """Mirror of the reference's DiffusionModel (diffusion_model.py:24-674)."""
+
+    def __init__(self, config: Dict):
+        super().__init__()
+        self.config = config
+        self.logger = logging.getLogger(__name__)
+
+        self.input_dim = config.get('input_dim', 512)
+        self.hidden_dim = config.get('hidden_dim', 256)
+        self.output_dim = config.get('output_dim', 128)
+        self.num_timesteps = config.get('num_timesteps', 1000)
+
+        self.use_mixed_precision = config.get('use_mixed_precision', True)
+        self.gradient_accumulation_steps = config.get('gradient_accumulation_steps', 1)
+        self.max_batch_size = config.get('max_batch_size', 32)
+        self.enable_memory_efficient_attention = config.get('enable_memory_efficient_attention', True)
+        # mixed precision on MI355X = bfloat16 MFMA operands with float32 accumulation; 'compute_dtype'
+        # ('bf16' / 'fp32') overrides the reference's boolean when given
+        self.compute_dtype = config.get('compute_dtype', 'bf16' if self.use_mixed_precision else 'fp32')
+        ops.dtype_code(self.compute_dtype)
+
+        self.device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+        self.model = UNetModel(
+            input_dim=self.input_dim,
+            hidden_dim=self.hidden_dim,
+            output_dim=self.output_dim,
+            num_timesteps=self.num_timesteps,
+            enable_memory_efficient_attention=self.enable_memory_efficient_attention,
+            compute_dtype=self.compute_dtype,
+        ).to(self.device)
+
+        # schedule tables: computed on the host with the reference's own expressions (:57-60), then moved
+        self.beta_schedule = self._create_beta_schedule()
+        self.alpha = 1.0 - self.beta_schedule
+        self.alpha_cumprod = torch.cumprod(self.alpha, dim=0)
+        self.alpha_cumprod_prev = F.pad(self.alpha_cumprod[:-1], (1, 0), value=1.0)
+        self._host = dict(beta=self.beta_schedule.clone(), alpha=self.alpha.clone(), alpha_cumprod=self.alpha_cumprod.clone(),
+                          alpha_cumprod_prev=self.alpha_cumprod_prev.clone())
+        self.beta_schedule = self.beta_schedule.to(self.device)
+        self.alpha = self.alpha.to(self.device)
+        self.alpha_cumprod = self.alpha_cumprod.to(self.device)
+        self.alpha_cumprod_prev = self.alpha_cumprod_prev.to(self.device)
+        self._tables = {}
+
+        optimizer_class = AdamW if config.get('use_adamw', True) else Adam
+        self.optimizer = optimizer_class(self.model.parameters(), lr=config.get('learning_rate', 1e-4),
+                                         weight_decay=config.get('weight_decay', 1e-2))
+        if config.get('use_onecycle', False):
+            self.scheduler = OneCycleLR(self.optimizer, max_lr=config.get('learning_rate', 1e-4),
+                                        total_steps=config.get('total_steps', 10000))
+        else:
+            self.scheduler = CosineAnnealingLR(self.optimizer, T_max=config.get('max_epochs', 100))
+        self.scaler = None   # bfloat16 needs no loss scaling; kept as an attribute of the reference's surface
+
+        self.memory_threshold = config.get('memory_threshold', 0.85)
+        self.gc_frequency = config.get('gc_frequency', 50)
+        self.operation_count = 0
+        self.memory_monitor_enabled = config.get('memory_monitor_enabled', True)
+        self.memory_check_interval = config.get('memory_check_interval', 10)
+        self.logger.info("diffusion model ready, device: %s, compute dtype: %s", self.device, self.compute_dtype)
+
+    # ---- schedule ---------------------------------------------------------------------------
+    def _create_beta_schedule(self, schedule_type: str = 'linear') -> torch.Tensor:
+        """diffusion_model.py:110-126 (always called with the default 'linear', :57)."""
+        if schedule_type == 'linear':
+            beta_start = self.config.get('beta_start', 1e-4)
+            beta_end = self.config.get('beta_end', 2e-2)
+            return torch.linspace(beta_start, beta_end, self.num_timesteps)
+        elif schedule_type == 'cosine':
+            return self._cosine_beta_schedule()
+        else:
+            raise ValueError(f"unsupported schedule type: {schedule_type}")
+
+    def _cosine_beta_schedule(self, s: float = 0.008) -> torch.Tensor:
+        """diffusion_model.py:128-142 (unreachable from the constructor, kept for the surface)."""
+        steps = self.num_timesteps + 1
+        x = torch.linspace(0, self.num_timesteps, steps)
+        alphas_cumprod = torch.cos(((x / self.num_timesteps) + s) / (1 + s) * math.pi * 0.5) ** 2
+        alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+        betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+        return torch.clip(betas, 0, 0.999)
+
+    def _posterior_variance(self) -> torch.Tensor:
+        """diffusion_model.py:509-519."""
+        posterior_variance = self.beta_schedule * (1.0 - self.alpha_cumprod_prev) / (1.0 - self.alpha_cumprod)
+        return torch.clamp(posterior_variance, min=1e-20)
+
+    def _extract(self, a: torch.Tensor, t: torch.Tensor, x_shape: Tuple) -> torch.Tensor:
+        """diffusion_model.py:494-507, gathering on the table's own device."""
+        batch_size = t.shape[0]
+        out = a.gather(-1, t.to(a.device))
+        return out.reshape(batch_size, *((1,) * (len(x_shape) - 1))).to(t.device)
+
+    def _host_tables(self):
+        """Per-timestep scalars of the sampler, evaluated on the host with the reference's expressions
+        (:197-201, :214-216) so they round exactly as they do there."""
+        if "ddpm" not in self._tables:
+            h = self._host
+            pv = torch.clamp(h["beta"] * (1.0 - h["alpha_cumprod_prev"]) / (1.0 - h["alpha_cumprod"]), min=1e-20)
+            sigma = torch.sqrt(pv)
+            sigma[0] = 0.0   # the t == 0 branch returns the mean (:211-212)
+            self._tables["ddpm"] = dict(beta=h["beta"], s1m=torch.sqrt(1.0 - h["alpha_cumprod"]),
+                                        sra=torch.sqrt(1.0 / h["alpha"]), sigma=sigma)
+        return self._tables["ddpm"]
+
+    def _ddpm_coef_array(self):
+        if "ddpm_c" not in self._tables:
+            tb = self._host_tables()
+            arr = (_lib.DdpmCoef * self.num_timesteps)()
+            for i in range(self.num_timesteps):
+                arr[i] = _lib.DdpmCoef(tb["sra"][i].item(), tb["beta"][i].item(), tb["s1m"][i].item(), tb["sigma"][i].item())
+            self._tables["ddpm_c"] = arr
+        return self._tables["ddpm_c"]
+
+    def _device_tables(self):
+        if "dev" not in self._tables:
+            self._tables["dev"] = dict(sqrt_ac=torch.sqrt(self._host["alpha_cumprod"]).to(self.device),
+                                       sqrt_1mac=torch.sqrt(1.0 - self._host["alpha_cumprod"]).to(self.device))
+        return self._tables["dev"]
+
+    # ---- forward process and loss -----------------------------------------------------------
+    def q_sample(self, x_start: torch.Tensor, t: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """diffusion_model.py:144-163."""
+        dv = self._device_tables()
+        seed = _seed_from_torch() if noise is None else 0
+        return ops.q_sample(x_start.to(torch.float32).contiguous(), t.to(torch.int64).contiguous(), dv["sqrt_ac"], dv["sqrt_1mac"],
+                            noise=noise.contiguous() if noise is not None else None, seed=seed)
+
+    def p_losses(self, x_start: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None,
+                 noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """diffusion_model.py:165-184 (forward value; the training step is not built on this path yet)."""
+        dv = self._device_tables()
+        x_noisy, used = ops.q_sample(x_start.to(torch.float32).contiguous(), t.to(torch.int64).contiguous(), dv["sqrt_ac"],
+                                     dv["sqrt_1mac"], noise=noise.contiguous() if noise is not None else None,
+                                     seed=_seed_from_torch() if noise is None else 0, return_noise=True)
+        predicted_noise = self.model(x_noisy, t, condition)
+        return F.mse_loss(used, predicted_noise)
+
+    # ---- reverse process --------------------------------------------------------------------
+    def p_sample(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None,
+                 noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One reverse step (diffusion_model.py:186-216).  Like the reference, which branches on t[0],
+        this expects one timestep for the whole batch."""
+        ts = int(t[0].item())
+        if not bool((t == ts).all().item()):
+            raise ValueError("p_sample expects a batch-uniform timestep (the reference branches on t[0] == 0)")
+        predicted_noise = self.model(x, t, condition)
+        c = self._ddpm_coef_array()[ts]
+        return ops.ddpm_step(x.to(torch.float32).contiguous(), predicted_noise,
+                             (c.sqrt_recip_alpha, c.beta, c.sqrt_one_minus_ac, c.sigma),
+                             noise=noise.contiguous() if noise is not None else None,
+                             seed=_seed_from_torch() if noise is None else 0, step=ts)
+
+    def _sampling_setup(self, batch, condition):
+        dev = self.model._device()
+        eng = self.model.engine(self.compute_dtype)
+        handle = eng.ensure(dev)
+        cemb = None
+        if condition is not None:
+            cemb = self.model.condition_embedding(condition.to(dev), self.compute_dtype)
+        ws, ws_bytes = eng.workspace_for(batch, dev)
+        return dev, eng, handle, cemb, ws, ws_bytes
+
+    def p_sample_loop(self, shape: Tuple, condition: Optional[torch.Tensor] = None, *, x_T: Optional[torch.Tensor] = None,
+                      noise: Optional[torch.Tensor] = None, seed: Optional[int] = None, row_offset: int = 0,
+                      t_start: Optional[int] = None, t_stop: int = 0) -> torch.Tensor:
+        """The T-step reverse loop (diffusion_model.py:218-261) as ONE native call.
+
+        Keyword-only extensions (defaults reproduce the reference's call): x_T gives the initial latent,
+        noise a [steps, B, D] tensor of injected per-step noise (execution order), seed / row_offset
+        select the counter-RNG stream of this batch (row_offset = index of its first row in a sharded
+        job), t_start / t_stop bound the timestep range."""
+        b, d = int(shape[0]), int(shape[1])
+        dev, eng, handle, cemb, ws, ws_bytes = self._sampling_setup(b, condition)
+        if seed is None:
+            seed = _seed_from_torch()
+        img = x_T.to(device=dev, dtype=torch.float32).clone().contiguous() if x_T is not None else \
+            ops.philox_normal(b, d, seed, _lib.STREAM_XT, 0, row_offset, dev)
+        first = self.num_timesteps - 1 if t_start is None else int(t_start)
+        stride = 0
+        if noise is not None:
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+            stride = noise.stride(0)
+        check(eng.lib.adcdiff_ddpm_sample_loop(handle, ops._ptr(img), img.stride(0), b, ops._ptr(cemb), self.hidden_dim,
+                                               self._ddpm_coef_array(), first, int(t_stop), ops._ptr(noise), stride, seed,
+                                               row_offset, ws, ws_bytes, ops._stream()))
+        return img
+
+    def _p_sample_loop_chunk(self, img: torch.Tensor, condition: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """diffusion_model.py:263-281 (the reference's version reads a missing attribute)."""
+        return self.p_sample_loop(tuple(img.shape), condition, x_T=img)
+
+    def sample(self, batch_size: int, condition: Optional[torch.Tensor] = None, use_ddim: bool = True, ddim_steps: int = 50,
+               eta: float = 0.0, **kw) -> torch.Tensor:
+        """diffusion_model.py:283-304."""
+        with torch.no_grad():
+            shape = (batch_size, self.output_dim)
+            self.operation_count += 1
+            if use_ddim:
+                return self.ddim_sample_loop(shape, condition, ddim_steps, eta, **kw)
+            return self.p_sample_loop(shape, condition, **kw)
+
+    def _make_ddim_timesteps(self, ddim_steps: int) -> torch.Tensor:
+        """diffusion_model.py:371-377."""
+        c = self.num_timesteps // ddim_steps
+        return (torch.arange(0, ddim_steps) * c + 1).to(self.device)
+
+    def _ddim_plan(self, ddim_steps, eta):
+        """(timesteps, coefficient array) in execution order; scalars evaluated on the host with the
+        reference's float32 expressions (diffusion_model.py:315-316, 325, 351-363)."""
+        c = self.num_timesteps // ddim_steps
+        ts = torch.arange(0, ddim_steps) * c + 1
+        prev = torch.cat([torch.tensor([0]), ts[:-1]])
+        ac = self._host["alpha_cumprod"]
+        n = ddim_steps
+        steps = (C.c_int * n)()
+        coef = (_lib.DdimCoef * n)()
+        for i, (t, tp) in enumerate(zip(ts.flip(0).tolist(), prev.flip(0).tolist())):
+            alpha_t, alpha_t_prev = ac[t], ac[tp]
+            c_eps = torch.sqrt(1 - alpha_t)
+            dir_coef = torch.sqrt(1 - alpha_t_prev - eta ** 2 * (1 - alpha_t_prev) / (1 - alpha_t) * (1 - alpha_t / alpha_t_prev))
+            sigma = eta * torch.sqrt((1 - alpha_t_prev) / (1 - alpha_t)) * torch.sqrt(1 - alpha_t / alpha_t_prev) if eta > 0 \
+                else torch.tensor(0.0)
+            steps[i] = t
+            coef[i] = _lib.DdimCoef(c_eps.item(), torch.sqrt(alpha_t).item(), torch.sqrt(alpha_t_prev).item(), dir_coef.item(),
+                                    float(sigma))
+        return steps, coef
+
+    def ddim_sample_loop(self, shape: Tuple, condition: Optional[torch.Tensor] = None, ddim_steps: int = 50, eta: float = 0.0, *,
+                         x_T: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, seed: Optional[int] = None,
+                         row_offset: int = 0) -> torch.Tensor:
+        """DDIM loop (diffusion_model.py:306-340), the generator's default sampler, as one native call."""
+        b, d = int(shape[0]), int(shape[1])
+        dev, eng, handle, cemb, ws, ws_bytes = self._sampling_setup(b, condition)
+        if seed is None:
+            seed = _seed_from_torch()
+        img = x_T.to(device=dev, dtype=torch.float32).clone().contiguous() if x_T is not None else \
+            ops.philox_normal(b, d, seed, _lib.STREAM_XT, 0, row_offset, dev)
+        steps, coef = self._ddim_plan(ddim_steps, eta)
+        stride = 0
+        if noise is not None:
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+            stride = noise.stride(0)
+        check(eng.lib.adcdiff_ddim_sample_loop(handle, ops._ptr(img), img.stride(0), b, ops._ptr(cemb), self.hidden_dim, steps, coef,
+                                               ddim_steps, ops._ptr(noise), stride, seed, row_offset, ws, ws_bytes, ops._stream()))
+        return img
+
+    def _ddim_sample_chunked(self, shape: Tuple, condition: Optional[torch.Tensor] = None, ddim_steps: int = 50,
+                             eta: float = 0.0) -> torch.Tensor:
+        """diffusion_model.py:379-399: chunking is unnecessary here, the whole batch runs at once."""
+        return self.ddim_sample_loop(shape, condition, ddim_steps, eta)
+
+    def ddim_step(self, x: torch.Tensor, t: torch.Tensor, t_prev: torch.Tensor, condition: Optional[torch.Tensor] = None,
+                  eta: float = 0.0, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """diffusion_model.py:342-369 for batch-uniform t / t_prev."""
+        ts, tp = int(t[0].item()), int(t_prev[0].item())
+        noise_pred = self.model(x, t, condition)
+        ac = self._host["alpha_cumprod"]
+        alpha_t, alpha_t_prev = ac[ts], ac[tp]
+        dir_coef = torch.sqrt(1 - alpha_t_prev - eta ** 2 * (1 - alpha_t_prev) / (1 - alpha_t) * (1 - alpha_t / alpha_t_prev))
+        sigma = float(eta * torch.sqrt((1 - alpha_t_prev) / (1 - alpha_t)) * torch.sqrt(1 - alpha_t / alpha_t_prev)) if eta > 0 else 0.0
+        coef = (torch.sqrt(1 - alpha_t).item(), torch.sqrt(alpha_t).item(), torch.sqrt(alpha_t_prev).item(), dir_coef.item(), sigma)
+        return ops.ddim_step(x.to(torch.float32).contiguous(), noise_pred, coef, noise=noise,
+                             seed=_seed_from_torch() if (noise is None and eta > 0) else 0, step=ts)
+
+    # ---- training -----------------------------------------------------------------------------
+    def train_step(self, x: torch.Tensor, step: int = 0) -> Dict[str, float]:
+        """diffusion_model.py:401-471.  The backward kernels of the denoiser are not built yet, so this
+        raises instead of silently running a PyTorch implementation."""
+        raise NotImplementedError("train_step needs the denoiser's backward HIP kernels, which are not built yet")
+
+    # ---- checkpoint ---------------------------------------------------------------------------
+    def save_model(self, path: str):
+        """Same checkpoint dict as the reference (diffusion_model.py:521-532)."""
+        torch.save({'model_state_dict': self.model.state_dict(), 'optimizer_state_dict': self.optimizer.state_dict(),
+                    'config': self.config}, path)
+        self.logger.info("model saved to %s", path)
+
+    def load_model(self, path: str):
+        """diffusion_model.py:534-543."""
+        checkpoint = torch.load(path, map_location=self.device)
+        self.model.load_state_dict(checkpoint['model_state_dict'])
+        self.optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
+        self.logger.info("model loaded from %s", path)
+
+    # ---- housekeeping of the reference's surface ------------------------------------------------
+    def _get_memory_usage(self) -> Dict[str, float]:
+        """diffusion_model.py:629-647."""
+        info = {'system_memory_percent': psutil.virtual_memory().percent / 100.0}
+        if torch.cuda.is_available():
+            used = torch.cuda.memory_allocated() / 1024 ** 3
+            total = torch.cuda.get_device_properties(0).total_memory / 1024 ** 3
+            info['gpu_memory_percent'] = used / total if total > 0 else 0.0
+            info['gpu_memory_used_gb'] = used
+        return info
+
+    def cleanup_resources(self):
+        """diffusion_model.py:649-667."""
+        for eng in self.model._engines.values():
+            eng.destroy()
+            eng.arena = eng.workspace = None
+        self.model._engines.clear()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        gc.collect()

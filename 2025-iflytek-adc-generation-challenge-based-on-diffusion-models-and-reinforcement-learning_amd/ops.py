@@ -1,0 +1,148 @@
+"""Tensor-level wrappers over the C ABI (include/adcdiff.h).
+
+torch is used here for device memory and the current stream only; every arithmetic step is a call
+into libadcdiff.so.  All functions require CUDA (ROCm) tensors and raise otherwise: there is no CPU
+path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, AdcdiffError, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise AdcdiffError("adcdiff kernels run on an MI355X only; got a %s tensor (no CPU fallback exists)" % t.device)
+
+
+def dtype_code(name):
+    if name in (BF16, "bf16", "bfloat16", torch.bfloat16):
+        return BF16
+    if name in (F32, "fp32", "f32", "float32", torch.float32):
+        return F32
+    raise ValueError("compute dtype must be 'bf16' or 'fp32', got %r" % (name,))
+
+
+def _pad_rows(n):
+    return (n + 127) // 128 * 128
+
+
+def _operand(x, code):
+    """Copy a [B, K] float32 tensor into a row-padded operand buffer of the GEMM's type."""
+    B, K = x.shape
+    buf = torch.zeros((_pad_rows(B), K), device=x.device, dtype=torch.bfloat16 if code == BF16 else torch.float32)
+    buf[:B].copy_(x)
+    return buf
+
+
+def gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, act=0, out_bf16=False, m_valid=None,
+         dtype="fp32"):
+    """out = act([A0|A1|A2] @ w.T + bias + rowbias + residual) through adcdiff_gemm.
+
+    a_list: operand tensors [M, K_s] (M a multiple of 128) already in the operand dtype; w [N, sum K_s]."""
+    lib = _lib.load()
+    code = dtype_code(dtype)
+    _need_gpu(w, *a_list)
+    M = a_list[0].shape[0]
+    N = w.shape[0]
+    args = _lib.GemmArgs()
+    args.dtype, args.M, args.N, args.nseg = code, M, N, len(a_list)
+    args.m_valid = 0 if m_valid is None else int(m_valid)
+    for i, a in enumerate(a_list):
+        args.A[i], args.lda[i], args.K[i] = a.data_ptr(), a.stride(0), a.shape[1]
+    args.W, args.ldw = w.data_ptr(), w.stride(0)
+    args.bias = bias.data_ptr() if bias is not None else None
+    if rowbias is not None:
+        args.rowbias = rowbias.data_ptr()
+        args.ldrb = 0 if rowbias.dim() == 1 else rowbias.stride(0)
+    args.rowbias_idx = rowbias_idx.data_ptr() if rowbias_idx is not None else None
+    if residual is not None:
+        args.residual, args.ldr = residual.data_ptr(), residual.stride(0)
+    args.act = act
+    rows = M
+    if out_bf16:
+        out = torch.empty((rows, N), device=w.device, dtype=torch.bfloat16)
+        args.out_bf16, args.ldo_bf16 = out.data_ptr(), N
+    else:
+        out = torch.empty((rows, N), device=w.device, dtype=torch.float32)
+        args.out_f32, args.ldo_f32 = out.data_ptr(), N
+    check(lib.adcdiff_gemm(C.byref(args), _stream()))
+    return out
+
+
+def linear(x, weight, bias, act=0, dtype="fp32"):
+    """nn.Linear on [B, K] float32 input (any B); returns [B, N] float32."""
+    code = dtype_code(dtype)
+    B = x.shape[0]
+    a = _operand(x.contiguous(), code)
+    w = weight.detach().to(torch.bfloat16 if code == BF16 else torch.float32).contiguous()
+    out = gemm([a], w, bias=bias.detach() if bias is not None else None, act=act, m_valid=B, dtype=dtype)
+    return out[:B]
+
+
+def groupnorm_silu(x, groups, gamma, beta, eps=1e-5, out_dtype="fp32", with_raw=False):
+    lib = _lib.load()
+    _need_gpu(x, gamma, beta)
+    code = dtype_code(out_dtype)
+    M, Cc = x.shape
+    td = torch.bfloat16 if code == BF16 else torch.float32
+    out = torch.empty((M, Cc), device=x.device, dtype=td)
+    raw = torch.empty((M, Cc), device=x.device, dtype=td) if with_raw else None
+    check(lib.adcdiff_groupnorm_silu(_ptr(x), x.stride(0), M, Cc, groups, _ptr(gamma), _ptr(beta), eps, code, _ptr(out), Cc,
+                                     _ptr(raw), Cc, _stream()))
+    return (out, raw) if with_raw else out
+
+
+def philox_normal(rows, cols, seed, stream_id, step, row_offset=0, device="cuda"):
+    lib = _lib.load()
+    out = torch.empty((rows, cols), device=device, dtype=torch.float32)
+    _need_gpu(out)
+    check(lib.adcdiff_philox_normal(_ptr(out), cols, rows, cols, seed, stream_id, step, row_offset, _stream()))
+    return out
+
+
+def ddpm_step(x, eps, coef, noise=None, seed=0, step=0, row_offset=0, out=None):
+    lib = _lib.load()
+    _need_gpu(x, eps, noise)
+    B, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    c = _lib.DdpmCoef(*[float(v) for v in coef])
+    check(lib.adcdiff_ddpm_step(_ptr(x), x.stride(0), _ptr(eps), eps.stride(0), _ptr(noise), noise.stride(0) if noise is not None else 0,
+                                _ptr(out), out.stride(0), B, D, c, seed, step, row_offset, _stream()))
+    return out
+
+
+def ddim_step(x, eps, coef, noise=None, seed=0, step=0, row_offset=0, out=None):
+    lib = _lib.load()
+    _need_gpu(x, eps, noise)
+    B, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    c = _lib.DdimCoef(*[float(v) for v in coef])
+    check(lib.adcdiff_ddim_step(_ptr(x), x.stride(0), _ptr(eps), eps.stride(0), _ptr(noise), noise.stride(0) if noise is not None else 0,
+                                _ptr(out), out.stride(0), B, D, c, seed, step, row_offset, _stream()))
+    return out
+
+
+def q_sample(x0, t, sqrt_ac, sqrt_1mac, noise=None, seed=0, step=0, row_offset=0, return_noise=False):
+    lib = _lib.load()
+    _need_gpu(x0, t, sqrt_ac, sqrt_1mac, noise)
+    B, D = x0.shape
+    out = torch.empty_like(x0)
+    nz_out = torch.empty_like(x0) if return_noise else None
+    check(lib.adcdiff_q_sample(_ptr(x0), x0.stride(0), _ptr(t), _ptr(sqrt_ac), _ptr(sqrt_1mac), sqrt_ac.numel(), _ptr(noise),
+                               noise.stride(0) if noise is not None else 0, _ptr(out), D, _ptr(nz_out), D, B, D, seed, step,
+                               row_offset, _stream()))
+    return (out, nz_out) if return_noise else out

@@ -1,0 +1,181 @@
+/*
+ * adcdiff.h -- C ABI of the MI355X (gfx950) DDPM sampling library.
+ *
+ * The reference (zhangmask/2025-iFlytek-ADC-Generation-Challenge-...) has no FFI, plugin or
+ * operator layer: its hot path is the Python class surface of src/models/diffusion_model.py.
+ * Each entry point below therefore cites the reference Python it replaces (file:line under
+ * the reference root); the Python mirror of that class surface (package
+ * models/diffusion_model.py) is the only caller.
+ *
+ * Conventions
+ *   - every function returns 0 (ADCDIFF_OK) or a negative ADCDIFF_E_* code and never throws;
+ *     adcdiff_last_error() returns a thread-local message for the last failure;
+ *   - all tensor arguments are caller-owned DEVICE pointers, row-major, leading dimensions in
+ *     elements; the library allocates no device memory: packed weights live in a caller
+ *     provided arena, intermediates in a caller provided workspace;
+ *   - every call only enqueues work on the given stream (a hipStream_t passed as void*, NULL =
+ *     the null stream) and returns without synchronising;
+ *   - ADCDIFF_F32 computes with float32 operands on v_mfma_f32_32x32x2_f32, ADCDIFF_BF16 with
+ *     bfloat16 operands on v_mfma_f32_32x32x16_bf16; accumulation, GroupNorm statistics, the
+ *     latent x_t and the schedule update are float32 in both.
+ */
+#ifndef ADCDIFF_H
+#define ADCDIFF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADCDIFF_ABI_VERSION 1
+
+enum { ADCDIFF_OK = 0, ADCDIFF_E_BADARG = -1, ADCDIFF_E_LAUNCH = -2, ADCDIFF_E_ARCH = -3, ADCDIFF_E_WORKSPACE = -4 };
+enum { ADCDIFF_F32 = 0, ADCDIFF_BF16 = 1 };
+
+/* Philox stream ids of the noise definition (counter = (col/4, row, step, stream)). */
+enum { ADCDIFF_STREAM_XT = 1, ADCDIFF_STREAM_STEP = 2, ADCDIFF_STREAM_QNOISE = 3, ADCDIFF_STREAM_TDRAW = 4 };
+
+typedef void* adcdiff_stream_t;
+
+int adcdiff_abi_version(void);
+const char* adcdiff_last_error(void);
+
+/* ------------------------------------------------------------------ single kernels ---- */
+
+/* out = act( [A0 | A1 | A2] * W^T + bias + rowbias + residual ): nn.Linear (diffusion_model.py:852-853,
+ * 799-800, 695-697, 733, 871) with the K dimension split over up to three A operands, which is how
+ * torch.cat([h, skip]) (:782) and linear2 + residual_proj (:885, :899, :907) are consumed without
+ * materialising the concatenation.  W is [N, K0+K1+K2] row-major (nn.Linear layout).
+ * Requirements: M % 128 == 0, N % 64 == 0, every K_s a multiple of 32 (F32) / 64 (BF16), all pointers
+ * 16-byte aligned, lda * sizeof(operand) % 16 == 0. */
+typedef struct adcdiff_gemm_args {
+    int dtype;                 /* operand type of A and W: ADCDIFF_F32 / ADCDIFF_BF16 */
+    int M, N;
+    int m_valid;               /* rows >= m_valid are computed but not read from rowbias_idx/residual nor stored; 0 = M */
+    int nseg;                  /* 1..3 */
+    const void* A[3];
+    int lda[3];
+    int K[3];
+    const void* W;
+    int ldw;
+    const float* bias;         /* [N] or NULL */
+    const float* rowbias;      /* NULL, or a table added per output row: row r reads
+                                  rowbias[(rowbias_idx ? rowbias_idx[r] : r) * ldrb + n];
+                                  ldrb == 0 broadcasts one row (the hoisted time_proj term, :893) */
+    long long ldrb;
+    const int64_t* rowbias_idx;/* [M] timestep per row, or NULL */
+    const float* residual;     /* float32 [M, N] added to the result (Identity residual, :873), or NULL */
+    int ldr;
+    int act;                   /* 0 none, 1 SiLU on the result (:820) */
+    float* out_f32;            /* optional float32 output */
+    int ldo_f32;
+    void* out_bf16;            /* optional bfloat16 output */
+    int ldo_bf16;
+} adcdiff_gemm_args;
+int adcdiff_gemm(const adcdiff_gemm_args* args, adcdiff_stream_t stream);
+
+/* out = SiLU(GroupNorm(x)) for x [M, C] float32 with `groups` contiguous channel groups, biased variance,
+ * eps inside the root (nn.GroupNorm + F.silu, diffusion_model.py:888-889, 896-897, 786-787).  out has
+ * out_dtype; raw_out (optional, same dtype) receives x itself converted to that type: the
+ * residual_proj operand (:885). */
+int adcdiff_groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const float* gamma,
+                           const float* beta, float eps, int out_dtype, void* out, int ldo,
+                           void* raw_out, int ldraw, adcdiff_stream_t stream);
+
+/* N(0,1) noise of the shared definition: out[r, c] for global row row_offset + r. cols % 4 == 0. */
+int adcdiff_philox_normal(float* out, int ld, int rows, int cols, uint64_t seed, uint32_t stream_id,
+                          uint32_t step, uint64_t row_offset, adcdiff_stream_t stream);
+
+/* One reverse step for a batch-uniform timestep (diffusion_model.py:197-216):
+ *   mean = sqrt_recip_alpha * (x - beta * eps / sqrt_one_minus_ac);  out = mean + sigma * z
+ * z = noise[r, c] when noise != NULL, else Philox (seed, ADCDIFF_STREAM_STEP, step, row_offset + r);
+ * sigma == 0 (the t == 0 branch, :211-212) draws nothing.  out may alias x. */
+typedef struct adcdiff_ddpm_coef { float sqrt_recip_alpha, beta, sqrt_one_minus_ac, sigma; } adcdiff_ddpm_coef;
+int adcdiff_ddpm_step(const float* x, int ldx, const float* eps, int lde, const float* noise, int ldn,
+                      float* out, int ldo, int B, int D, adcdiff_ddpm_coef coef, uint64_t seed,
+                      uint32_t step, uint64_t row_offset, adcdiff_stream_t stream);
+
+/* One DDIM step (diffusion_model.py:350-369):
+ *   pred_x0 = (x - c_eps * eps) / sqrt_ac_t;  out = sqrt_ac_prev * pred_x0 + dir_coef * eps + sigma * z */
+typedef struct adcdiff_ddim_coef { float c_eps, sqrt_ac_t, sqrt_ac_prev, dir_coef, sigma; } adcdiff_ddim_coef;
+int adcdiff_ddim_step(const float* x, int ldx, const float* eps, int lde, const float* noise, int ldn,
+                      float* out, int ldo, int B, int D, adcdiff_ddim_coef coef, uint64_t seed,
+                      uint32_t step, uint64_t row_offset, adcdiff_stream_t stream);
+
+/* Forward diffusion with per-row timesteps (diffusion_model.py:144-163):
+ *   out = sqrt_ac[t_r] * x0 + sqrt_one_minus_ac[t_r] * z;  z = noise or Philox (ADCDIFF_STREAM_QNOISE, step).
+ * When noise_out != NULL the z that was used is written there (p_losses needs it as the target, :176-183). */
+int adcdiff_q_sample(const float* x0, int ldx, const int64_t* t, const float* sqrt_ac, const float* sqrt_one_minus_ac,
+                     int num_timesteps, const float* noise, int ldn, float* out, int ldo, float* noise_out,
+                     int ldno, int B, int D, uint64_t seed, uint32_t step, uint64_t row_offset,
+                     adcdiff_stream_t stream);
+
+/* ------------------------------------------------------------------ denoiser -------- */
+
+/* Float32 parameters of one ResidualBlock in the reference's layout (diffusion_model.py:849-873). */
+typedef struct adcdiff_block_params {
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+    const float *linear1_w, *linear1_b, *linear2_w, *linear2_b;
+    const float *time_proj_w, *time_proj_b;
+    const float *residual_w, *residual_b;   /* NULL when in_dim == out_dim (nn.Identity) */
+} adcdiff_block_params;
+
+/* UNetModel parameters (diffusion_model.py:690-733); blocks = encoder.0-3, middle.0-1, decoder.0-3. */
+typedef struct adcdiff_unet_params {
+    int input_dim, hidden_dim, output_dim, num_timesteps;
+    const float *time_lin1_w, *time_lin1_b, *time_lin2_w, *time_lin2_b;
+    const float *cond0_w, *cond0_b, *cond2_w, *cond2_b;
+    adcdiff_block_params blocks[10];
+    const float *out_norm_w, *out_norm_b, *out_w, *out_b;
+    const float* sinusoid_freq;   /* [hidden_dim / 2] float32: exp(arange(half) * -ln(1e4)/(half-1)) (:812-814) */
+} adcdiff_unet_params;
+
+typedef struct adcdiff_unet adcdiff_unet;   /* host-side plan: sizes and pointers into the arena */
+
+/* Bytes of device arena for packed weights and the per-timestep tables, and of workspace for a batch. */
+size_t adcdiff_unet_arena_bytes(int input_dim, int hidden_dim, int output_dim, int num_timesteps, int dtype);
+size_t adcdiff_unet_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int dtype, int batch);
+
+/* Create a plan over caller-owned parameters and arena (nothing is copied or launched). */
+int adcdiff_unet_create(const adcdiff_unet_params* params, int dtype, void* arena, size_t arena_bytes,
+                        adcdiff_unet** out);
+void adcdiff_unet_destroy(adcdiff_unet* net);
+
+/* (Re)pack the weights into the arena and rebuild the tables that depend only on the timestep:
+ * TimeEmbedding(t) (diffusion_model.py:802-823) and every block's time_proj(SiLU(.)) (:859-862, :893)
+ * for t = 0..num_timesteps-1.  Call after the parameters change.  workspace as for batch 1024. */
+int adcdiff_unet_pack(adcdiff_unet* net, void* workspace, size_t workspace_bytes, adcdiff_stream_t stream);
+
+/* condition_embed (diffusion_model.py:694-698, :765): cemb [B, hidden] float32. */
+int adcdiff_unet_condition_embed(adcdiff_unet* net, const float* cond, int ldc, int B, float* cemb, int ldce,
+                                 void* workspace, size_t workspace_bytes, adcdiff_stream_t stream);
+
+/* UNetModel.forward (diffusion_model.py:749-789): eps [B, output_dim] float32.
+ * t_rows (device int64 [B]) gives a timestep per row; when NULL every row uses t_uniform.
+ * cemb is the output of adcdiff_unet_condition_embed or NULL (unconditional). */
+int adcdiff_unet_forward(adcdiff_unet* net, const float* x, int ldx, int B, const int64_t* t_rows,
+                         int t_uniform, const float* cemb, int ldce, float* eps, int lde, void* workspace,
+                         size_t workspace_bytes, adcdiff_stream_t stream);
+
+/* p_sample_loop (diffusion_model.py:253-261): x holds x_T on entry and the result on return.
+ * coef is a HOST array indexed by timestep; steps run t_start, t_start-1, ..., t_stop.
+ * noise (optional, device) holds the injected noise of step t at noise + (t_start - t) * noise_step_stride
+ * as [B, D] with leading dimension D; NULL selects in-kernel Philox with (seed, row_offset). */
+int adcdiff_ddpm_sample_loop(adcdiff_unet* net, float* x, int ldx, int B, const float* cemb, int ldce,
+                             const adcdiff_ddpm_coef* coef, int t_start, int t_stop, const float* noise,
+                             long long noise_step_stride, uint64_t seed, uint64_t row_offset, void* workspace,
+                             size_t workspace_bytes, adcdiff_stream_t stream);
+
+/* ddim_sample_loop (diffusion_model.py:325-340): nsteps steps, timesteps[i] / coef[i] HOST arrays in
+ * execution order; noise layout as above indexed by execution step i. */
+int adcdiff_ddim_sample_loop(adcdiff_unet* net, float* x, int ldx, int B, const float* cemb, int ldce,
+                             const int* timesteps, const adcdiff_ddim_coef* coef, int nsteps, const float* noise,
+                             long long noise_step_stride, uint64_t seed, uint64_t row_offset, void* workspace,
+                             size_t workspace_bytes, adcdiff_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADCDIFF_H */

@@ -1,0 +1,82 @@
+"""CPU-side checks of the boundary: the shared library loads, exports every symbol the header declares,
+and the Python mirror keeps the reference's surface.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import adcdiff
+from adcdiff import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    header = open(os.path.join(ROOT, "include", "adcdiff.h")).read()
+    declared = set(re.findall(r"\b(adcdiff_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 17
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().adcdiff_abi_version() == 1
+
+
+def test_size_queries_and_argument_errors_without_gpu():
+    lib = _lib.load()
+    assert lib.adcdiff_unet_arena_bytes(512, 256, 512, 1000, _lib.BF16) > 88_000_000
+    assert lib.adcdiff_unet_workspace_bytes(512, 256, 512, _lib.BF16, 4096) > 0
+    assert lib.adcdiff_unet_arena_bytes(500, 256, 512, 1000, _lib.BF16) == 0
+    assert b"multiples of 64" in lib.adcdiff_last_error()
+    args = _lib.GemmArgs()
+    args.dtype, args.M, args.N, args.nseg = _lib.BF16, 100, 64, 1
+    assert lib.adcdiff_gemm(ctypes.byref(args), None) == -1
+    assert b"multiple of 128" in lib.adcdiff_last_error()
+
+
+def test_mirror_keeps_reference_surface(golden_a, golden_tiny):
+    cfg = {'input_dim': 512, 'hidden_dim': 256, 'output_dim': 512, 'num_timesteps': 1000, 'beta_start': 1e-4, 'beta_end': 2e-2}
+    m = adcdiff.DiffusionModel(cfg)
+    assert list(m.model.state_dict().keys()) == golden_a["state_dict_keys"].tolist()
+    assert sum(p.numel() for p in m.model.parameters()) == 44_323_584
+    for attr in ("input_dim", "hidden_dim", "output_dim", "num_timesteps", "device", "max_batch_size", "beta_schedule", "alpha",
+                 "alpha_cumprod", "alpha_cumprod_prev", "optimizer", "scheduler", "scaler"):
+        assert hasattr(m, attr), attr
+    for meth in ("q_sample", "p_losses", "p_sample", "p_sample_loop", "sample", "ddim_sample_loop", "ddim_step", "train_step",
+                 "save_model", "load_model", "cleanup_resources", "_extract", "_posterior_variance", "_make_ddim_timesteps"):
+        assert callable(getattr(m, meth)), meth
+    # schedule tables equal the reference's on this host (1 ulp allowed across CPU vector widths)
+    for name, key in (("beta_schedule", "beta"), ("alpha", "alpha"), ("alpha_cumprod", "alpha_cumprod"),
+                      ("alpha_cumprod_prev", "alpha_cumprod_prev")):
+        assert np.abs(getattr(m, name).cpu().numpy() - golden_tiny[key]).max() <= 6e-8, name
+    assert np.abs(m._posterior_variance().cpu().numpy() - golden_tiny["posterior_variance"]).max() <= 2e-9
+    assert m._make_ddim_timesteps(50).cpu().tolist() == golden_tiny["ddim_timesteps"].tolist()
+    assert np.abs(m.model.time_embed.frequencies().numpy() - golden_tiny["sinusoid_freq_h256"]).max() <= 6e-8
+    # reference initialisation: zero biases, unit GroupNorm weights (diffusion_model.py:738-747)
+    assert float(m.model.output_layer.bias.abs().max()) == 0.0
+    assert float((m.model.output_norm.weight - 1).abs().max()) == 0.0
+
+
+def test_checkpoint_round_trip(tmp_path):
+    cfg = {'input_dim': 128, 'hidden_dim': 128, 'output_dim': 128}
+    a = adcdiff.DiffusionModel(cfg)
+    path = str(tmp_path / "diffusion_model.pth")
+    a.save_model(path)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "config"}
+    b = adcdiff.DiffusionModel(cfg)
+    b.load_model(path)
+    for (k1, v1), (k2, v2) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu())
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the loud failure on a machine without a GPU")
+def test_no_cpu_fallback():
+    m = adcdiff.DiffusionModel({'input_dim': 128, 'hidden_dim': 128, 'output_dim': 128})
+    with pytest.raises(adcdiff.AdcdiffError):
+        m.sample(2, use_ddim=False)
+    with pytest.raises(adcdiff.AdcdiffError):
+        m.model(torch.zeros(2, 128), torch.zeros(2, dtype=torch.long))

@@ -1,0 +1,134 @@
+"""GPU parity of the single kernels against the oracle, called through the C ABI (via adcdiff.ops).
+
+Tolerances (relative to max(1, max|ref|) unless stated):
+* float32 GEMM: 2e-6 -- v_mfma_f32_32x32x2_f32 is an exact fma chain, only the summation order differs;
+* bfloat16 GEMM: compared with a float64 product of the SAME bf16-rounded operands, 1e-5; against the
+  unrounded float32 operands the error is the bf16 rounding itself (~2^-9 per operand), gate 2e-2;
+* GroupNorm+SiLU float32: 2e-6; bf16 output: 2^-8 relative rounding of the output;
+* schedule update / DDIM / q_sample with injected noise: bit-exact (built with -ffp-contract=off);
+* Philox noise: 4e-6 absolute (hardware log2 / sin / cos units against float64 libm).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import ddpm, philox
+
+pytestmark = pytest.mark.gpu
+
+adcdiff = pytest.importorskip("adcdiff")
+ops = adcdiff.ops
+DEV = "cuda"
+
+
+def _t(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+def _bf16_round(a):
+    return torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,Ks", [(128, 64, [64]), (256, 128, [128, 64]), (384, 192, [64, 128, 64]), (128, 256, [512])])
+def test_gemm_segments_and_epilogue(dtype, M, N, Ks):
+    rng = np.random.default_rng(7)
+    As = [rng.standard_normal((M, k)).astype(np.float32) for k in Ks]
+    W = (rng.standard_normal((N, sum(Ks))) / np.sqrt(sum(Ks))).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    table = rng.standard_normal((10, N)).astype(np.float32)
+    idx = rng.integers(0, 10, M).astype(np.int64)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    if dtype == "bf16":
+        As_r, W_r = [_bf16_round(a) for a in As], _bf16_round(W)
+    else:
+        As_r, W_r = As, W
+    ref = np.concatenate(As_r, 1).astype(np.float64) @ W_r.astype(np.float64).T + bias + table[idx] + res
+    out = ops.gemm([_t(a, td) for a in As], _t(W, td), bias=_t(bias), rowbias=_t(table), rowbias_idx=_t(idx, torch.int64),
+                   residual=_t(res), dtype=dtype)
+    assert rel_err(out.cpu().numpy(), ref) < (1e-5 if dtype == "bf16" else 2e-6)
+    # SiLU epilogue, broadcast row bias, bf16 output, partial store
+    ref2 = np.concatenate(As_r, 1).astype(np.float64) @ W_r.astype(np.float64).T + table[3]
+    ref2 = ref2 / (1 + np.exp(-ref2))
+    out2 = ops.gemm([_t(a, td) for a in As], _t(W, td), rowbias=_t(table[3]), act=1, out_bf16=True, m_valid=M - 5, dtype=dtype)
+    got = out2.float().cpu().numpy()
+    assert rel_err(got[:M - 5], ref2[:M - 5]) < 8e-3
+
+
+def test_gemm_asymmetric_layout():
+    """A = I against an asymmetric W catches a transposed or permuted accumulator map."""
+    M = N = K = 128
+    W = (np.arange(N)[:, None] * 3 + np.arange(K)[None, :] * 0.5).astype(np.float32)
+    for dtype, td in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        out = ops.gemm([_t(np.eye(M, K, dtype=np.float32), td)], _t(W, td), dtype=dtype).cpu().numpy()
+        assert np.array_equal(out, _bf16_round(W).T if dtype == "bf16" else W.T)
+
+
+@pytest.mark.parametrize("C,G", [(128, 32), (256, 32), (512, 32), (1024, 32), (2048, 32), (4096, 32), (192, 32), (64, 32), (2048, 16)])
+def test_groupnorm_silu(C, G):
+    rng = np.random.default_rng(C)
+    M = 37
+    x = (rng.standard_normal((M, C)) * 3 + 0.5).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    xg = x.astype(np.float64).reshape(M, G, C // G)
+    y = (xg - xg.mean(2, keepdims=True)) / np.sqrt(xg.var(2, keepdims=True) + 1e-5)
+    y = y.reshape(M, C) * gamma + beta
+    ref = y / (1 + np.exp(-y))
+    out = ops.groupnorm_silu(_t(x), G, _t(gamma), _t(beta), out_dtype="fp32")
+    assert rel_err(out.cpu().numpy(), ref) < 2e-6
+    outb, raw = ops.groupnorm_silu(_t(x), G, _t(gamma), _t(beta), out_dtype="bf16", with_raw=True)
+    assert np.abs(outb.float().cpu().numpy() - ref).max() <= 2.0 ** -8 * np.abs(ref).max() + 1e-6
+    assert np.array_equal(raw.float().cpu().numpy(), _bf16_round(x))
+
+
+def test_philox_noise_matches_oracle():
+    z = ops.philox_normal(64, 512, 2025, philox.STREAM_STEP, 7, row_offset=1000).cpu().numpy()
+    ref = philox.normal(2025, philox.STREAM_STEP, 7, 1000, 64, 512)
+    assert np.abs(z - ref).max() < 4e-6
+    z2 = ops.philox_normal(3, 128, (5 << 32) + 9, philox.STREAM_XT, 0).cpu().numpy()
+    assert np.abs(z2 - philox.normal((5 << 32) + 9, philox.STREAM_XT, 0, 0, 3, 128)).max() < 4e-6
+
+
+def test_schedule_update_bit_exact_with_injected_noise():
+    s = ddpm.make_schedule()
+    B, D = 33, 512
+    x = philox.normal(1, 50, 0, 0, B, D) * 5
+    eps = philox.normal(1, 51, 0, 0, B, D)
+    nz = philox.normal(1, philox.STREAM_STEP, 3, 0, B, D)
+    for i in (999, 500, 1, 0):
+        coef = (s["sqrt_recip_alpha"][i], s["beta"][i], s["sqrt_one_minus_alpha_cumprod"][i],
+                np.sqrt(s["posterior_variance"][i]) if i > 0 else 0.0)
+        out = ops.ddpm_step(_t(x), _t(eps), coef, noise=_t(nz)).cpu().numpy()
+        assert np.array_equal(out, ddpm.p_sample_update(s, x, eps, i, nz)), i
+        # in-kernel Philox noise: same update, noise equal to a few ulps
+        out2 = ops.ddpm_step(_t(x), _t(eps), coef, seed=77, step=i, row_offset=12).cpu().numpy()
+        ref2 = ddpm.p_sample_update(s, x, eps, i, philox.normal(77, philox.STREAM_STEP, i, 12, B, D))
+        assert np.abs(out2 - ref2).max() < 4e-6 * max(1.0, float(coef[3])) + 1e-6
+
+
+def test_ddim_and_q_sample_bit_exact():
+    s = ddpm.make_schedule()
+    B, D = 16, 256
+    x = philox.normal(2, 50, 0, 0, B, D) * 3
+    eps = philox.normal(2, 51, 0, 0, B, D)
+    nz = philox.normal(2, philox.STREAM_STEP, 3, 0, B, D)
+    one = np.float32(1)
+    for (t, tp), eta in (((981, 961), 0.0), ((21, 1), 0.5), ((1, 0), 0.5)):
+        a_t, a_p = s["alpha_cumprod"][t], s["alpha_cumprod"][tp]
+        e2 = np.float32(eta ** 2)
+        dir_coef = np.sqrt(one - a_p - e2 * (one - a_p) / (one - a_t) * (one - a_t / a_p))
+        sigma = np.float32(eta) * np.sqrt((one - a_p) / (one - a_t)) * np.sqrt(one - a_t / a_p) if eta > 0 else 0.0
+        coef = (np.sqrt(one - a_t), np.sqrt(a_t), np.sqrt(a_p), dir_coef, sigma)
+        out = ops.ddim_step(_t(x), _t(eps), coef, noise=_t(nz) if eta > 0 else None).cpu().numpy()
+        assert np.array_equal(out, ddpm.ddim_update(s, x, eps, t, tp, eta, nz)), (t, tp, eta)
+    t = np.array([0, 999, 5, 500] * 4, dtype=np.int64)
+    out, used = ops.q_sample(_t(x), _t(t, torch.int64), _t(s["sqrt_alpha_cumprod"]), _t(s["sqrt_one_minus_alpha_cumprod"]),
+                             noise=_t(nz), return_noise=True)
+    assert np.array_equal(out.cpu().numpy(), ddpm.q_sample(s, x, t, nz))
+    assert np.array_equal(used.cpu().numpy(), nz)
+    out, used = ops.q_sample(_t(x), _t(t, torch.int64), _t(s["sqrt_alpha_cumprod"]), _t(s["sqrt_one_minus_alpha_cumprod"]),
+                             seed=9, step=4, row_offset=2, return_noise=True)
+    assert np.abs(used.cpu().numpy() - philox.normal(9, philox.STREAM_QNOISE, 4, 2, B, D)).max() < 4e-6

@@ -1,0 +1,136 @@
+"""GPU parity of the denoiser and the reverse loops against the golden vectors (written by the
+reference) and the oracle, through the drop-in Python surface (which calls the C ABI).
+
+Stated tolerances, relative to max(1, max|ref|) over the compared tensor:
+* float32 path: 2e-5 for one denoiser forward, 1e-4 for final latents after T = 1000 steps (the
+  float32 numpy-vs-torch floor on the same data is 1e-6 / 4e-6);
+* bfloat16-operand path (float32 accumulate / statistics / latent): 3e-2 forward, 5e-2 final latents.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import ddpm, philox
+from oracle.weights import make_weights
+
+pytestmark = pytest.mark.gpu
+
+adcdiff = pytest.importorskip("adcdiff")
+SEED = 2025
+FWD_TOL = {"fp32": 2e-5, "bf16": 3e-2}
+LOOP_TOL = {"fp32": 1e-4, "bf16": 5e-2}
+
+
+def build(dims, dtype, T=1000):
+    cfg = dict(input_dim=dims[0], hidden_dim=dims[1], output_dim=dims[2], num_timesteps=T, beta_start=1e-4, beta_end=2e-2,
+               compute_dtype=dtype, memory_monitor_enabled=False)
+    m = adcdiff.DiffusionModel(cfg)
+    w = make_weights(1234, *dims)
+    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
+    return m, w
+
+
+def cu(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda").to(dtype)
+
+
+def injected(seed, B, D, steps):
+    return np.stack([philox.normal(seed, philox.STREAM_STEP, i, 0, B, D) for i in steps])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_tiny_forward_blocks_and_steps(dtype, golden_tiny):
+    g = golden_tiny
+    m, w = build((128, 128, 128), dtype)
+    x = philox.normal(SEED, 50, 0, 0, 8, 128)
+    cond = philox.normal(SEED, 51, 0, 0, 8, 128)
+    t = cu(g["fwd_t"], torch.int64)
+    y = m.model(cu(x), t).cpu().numpy()
+    assert rel_err(y, g["fwd_uncond"]) < FWD_TOL[dtype]
+    y = m.model(cu(x), t, cu(cond)).cpu().numpy()
+    assert rel_err(y, g["fwd_cond"]) < FWD_TOL[dtype]
+    te = m.model.time_embed(cu(g["time_embed_t"], torch.int64)).cpu().numpy()
+    assert rel_err(te, g["time_embed"]) < 2e-5
+    nz = philox.normal(SEED, philox.STREAM_QNOISE, 0, 0, 8, 128)
+    assert rel_err(m.q_sample(cu(x), t, cu(nz)).cpu().numpy(), g["q_sample"]) < 1e-6
+    for i in (999, 1, 0):
+        out = m.p_sample(cu(x), torch.full((8,), i, device="cuda", dtype=torch.long),
+                         noise=cu(philox.normal(SEED, philox.STREAM_STEP, i, 0, 8, 128))).cpu().numpy()
+        assert rel_err(out, g["p_sample_t%d" % i]) < FWD_TOL[dtype], i
+    out = m.p_sample(cu(x), torch.full((8,), 500, device="cuda", dtype=torch.long), cu(cond),
+                     noise=cu(philox.normal(SEED, philox.STREAM_STEP, 500, 0, 8, 128))).cpu().numpy()
+    assert rel_err(out, g["p_sample_cond_t500"]) < FWD_TOL[dtype]
+    if dtype == "fp32":
+        # single ResidualBlock modules through the single-kernel entry points
+        t_emb = cu(ddpm.time_embedding({**w, ddpm.FREQ_KEY: g["sinusoid_freq_h128"]}, g["fwd_t"], 128))
+        h = m.model.encoder[0](cu(x), t_emb).cpu().numpy()
+        assert rel_err(h, g["fwd_uncond_block.encoder.0"]) < FWD_TOL[dtype]
+        h1 = m.model.encoder[1](cu(g["fwd_uncond_block.encoder.0"]), t_emb).cpu().numpy()
+        assert rel_err(h1, g["fwd_uncond_block.encoder.1"]) < FWD_TOL[dtype]
+    nzl = cu(philox.normal(SEED, philox.STREAM_QNOISE, 0, 0, 8, 128))
+    loss = m.p_losses(cu(g["train_x0"]), cu(g["train_t"], torch.int64), noise=nzl)
+    assert abs(float(loss) - float(g["p_losses"])) < (1e-4 if dtype == "fp32" else 2e-2) * float(g["p_losses"])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_tiny_reverse_loops(dtype, golden_tiny):
+    g = golden_tiny
+    m, _ = build((128, 128, 128), dtype)
+    cond = philox.normal(SEED, 51, 0, 0, 8, 128)
+    xT = ddpm.philox_x_T(SEED, 0, 8, 128)
+    # injected noise (bit-identical to what the reference consumed)
+    out = m.sample(8, use_ddim=False, x_T=cu(xT), noise=cu(injected(SEED, 8, 128, range(999, 0, -1)))).cpu().numpy()
+    assert rel_err(out, g["loop_T1000"]) < LOOP_TOL[dtype]
+    # in-kernel Philox: the same definition evaluated on the GPU's transcendental units
+    out = m.sample(8, use_ddim=False, seed=SEED).cpu().numpy()
+    assert rel_err(out, g["loop_T1000"]) < LOOP_TOL[dtype]
+    out = m.sample(8, condition=cu(cond), use_ddim=False, seed=SEED + 1).cpu().numpy()
+    assert rel_err(out, g["loop_T1000_cond"]) < LOOP_TOL[dtype]
+    # the generator's 1-row condition repeated to the batch gives the same as passing it repeated
+    out = m.sample(8, use_ddim=True, ddim_steps=50, eta=0.0, seed=SEED).cpu().numpy()
+    assert rel_err(out, g["ddim50_eta0"]) < LOOP_TOL[dtype]
+    out = m.sample(8, condition=cu(cond), use_ddim=True, ddim_steps=50, eta=0.5, seed=SEED).cpu().numpy()
+    assert rel_err(out, g["ddim50_eta05_cond"]) < LOOP_TOL[dtype]
+    m50, _ = build((128, 128, 128), dtype, T=50)
+    out = m50.sample(8, use_ddim=False, seed=SEED).cpu().numpy()
+    assert rel_err(out, g["loop_T50"]) < LOOP_TOL[dtype]
+
+
+@pytest.mark.parametrize("name,dims", [("config_a", (512, 256, 512)), ("config_b", (512, 128, 512))])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_full_size_configs_against_reference(name, dims, dtype):
+    g = load_golden(name)
+    m, _ = build(dims, dtype)
+    cols = g["fwd.cols"]
+    x = philox.normal(SEED, 50, 0, 0, 32, 512)
+    y = m.model(cu(x), cu(g["fwd_t"], torch.int64)).cpu().numpy()
+    assert rel_err(y[:, cols], g["fwd.values"]) < FWD_TOL[dtype]
+    assert rel_err(np.sqrt((y.astype(np.float64) ** 2).sum(1)), g["fwd.row_norm"]) < FWD_TOL[dtype]
+    y = m.model(cu(x), torch.full((32,), 999, device="cuda", dtype=torch.long)).cpu().numpy()
+    assert rel_err(y[:, cols], g["fwd_t999.values"]) < FWD_TOL[dtype]
+    out = m.sample(32, use_ddim=False, seed=SEED).cpu().numpy()
+    assert np.isfinite(out).all()
+    assert rel_err(out[:, cols], g["loop_T1000.values"]) < LOOP_TOL[dtype]
+    assert rel_err(np.sqrt((out.astype(np.float64) ** 2).sum(1)), g["loop_T1000.row_norm"]) < LOOP_TOL[dtype]
+    out = m.sample(32, use_ddim=True, ddim_steps=50, seed=SEED).cpu().numpy()
+    assert rel_err(out[:, cols], g["ddim50.values"]) < LOOP_TOL[dtype]
+
+
+def test_batch_4096_rows_are_independent_and_shardable(golden_a):
+    """Config 2 (fp32, batch 4096): rows of a large batch equal the same rows sampled alone (bit for
+    bit), so the 32 golden rows pin the big batch; two shards with row offsets equal the unsharded run."""
+    g = golden_a
+    m, _ = build((512, 256, 512), "fp32")
+    steps = dict(t_start=999, t_stop=900)   # 100 steps keep the test short; the property is per step
+    big = m.p_sample_loop((4096, 512), seed=SEED, **steps)
+    small = m.p_sample_loop((32, 512), seed=SEED, **steps)
+    assert torch.equal(big[:32], small)
+    lo = m.p_sample_loop((2048, 512), seed=SEED, row_offset=0, **steps)
+    hi = m.p_sample_loop((2048, 512), seed=SEED, row_offset=2048, **steps)
+    assert torch.equal(torch.cat([lo, hi]), big)
+    odd = m.p_sample_loop((77, 512), seed=SEED, row_offset=4000, **steps)   # ragged batch, not a tile multiple
+    assert torch.equal(odd, big[4000:4077])
+    full = m.sample(4096, use_ddim=False, seed=SEED).cpu().numpy()
+    assert np.isfinite(full).all()
+    assert rel_err(full[:32][:, g["fwd.cols"]], g["loop_T1000.values"]) < LOOP_TOL["fp32"]
