@@ -46,6 +46,13 @@ class UnetParams(C.Structure):
                 ("sinusoid_freq", c_fp)]
 
 
+class TimingRecord(C.Structure):
+    _fields_ = [("kind", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ms", C.c_float), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+KIND_GEMM_F32, KIND_GEMM_BF16, KIND_GROUPNORM, KIND_UPDATE = 0, 1, 2, 3
+
 # name -> (restype, argtypes): every symbol include/adcdiff.h declares
 SIGNATURES = {
     "adcdiff_abi_version": (C.c_int, []),
@@ -73,6 +80,8 @@ SIGNATURES = {
     "adcdiff_ddim_sample_loop": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.POINTER(C.c_int),
                                            C.POINTER(DdimCoef), C.c_int, c_fp, C.c_longlong, C.c_uint64, C.c_uint64, c_fp,
                                            C.c_size_t, c_fp]),
+    "adcdiff_timing_begin": (C.c_int, [C.c_int]),
+    "adcdiff_timing_end": (C.c_int, [C.POINTER(TimingRecord), C.c_int, C.POINTER(C.c_int)]),
 }
 
 _lib = None

@@ -27,6 +27,14 @@ inline int check_launch(const char* what) {
     return ADCDIFF_OK;
 }
 
+// Brackets one launch with hipEvents while adcdiff_timing_begin/_end is active (see include/adcdiff.h).
+struct TimingScope {
+    int slot;
+    hipStream_t stream;
+    TimingScope(int kind, int M, int N, int K, double flops, double bytes, hipStream_t st);
+    ~TimingScope();
+};
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }

@@ -19,6 +19,27 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// ------------------------------------------------------------------ per-launch timing
+namespace {
+struct TimingState {
+    bool on = false;
+    int cap = 0, used = 0;
+    hipEvent_t* ev = nullptr;            // 2 * cap events
+    adcdiff_timing_record* rec = nullptr;
+} g_timing;
+}  // namespace
+
+TimingScope::TimingScope(int kind, int M, int N, int K, double flops, double bytes, hipStream_t st) : slot(-1), stream(st) {
+    if (!g_timing.on || g_timing.used >= g_timing.cap) return;
+    slot = g_timing.used++;
+    g_timing.rec[slot] = adcdiff_timing_record{kind, M, N, K, 0.0f, flops, bytes};
+    (void)hipEventRecord(g_timing.ev[2 * slot], stream);
+}
+
+TimingScope::~TimingScope() {
+    if (slot >= 0) (void)hipEventRecord(g_timing.ev[2 * slot + 1], stream);
+}
+
 // ------------------------------------------------------------------ GroupNorm + SiLU
 // One float4 (four channels) per thread; a group of gs channels spans gs/4 adjacent lanes, so the two
 // statistics passes (mean, then centred sum of squares) are xor-shuffle reductions over gs/4 lanes.
@@ -110,6 +131,8 @@ int groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const floa
                    int out_dtype, void* out, int ldo, void* raw_out, int ldraw, hipStream_t stream) {
     if (!x || !gamma || !beta || !out || M <= 0 || C <= 0 || groups <= 0 || C % groups != 0 || ldx < C || ldo < C)
         return fail(ADCDIFF_E_BADARG, "groupnorm_silu: bad arguments (M=%d C=%d groups=%d ldx=%d ldo=%d)", M, C, groups, ldx, ldo);
+    const double osz = out_dtype == ADCDIFF_BF16 ? 2.0 : 4.0;
+    TimingScope ts(ADCDIFF_KIND_GROUPNORM, M, C, 0, 0.0, (double)M * C * (4.0 + osz * (raw_out ? 2 : 1)), stream);
     if (raw_out && ldraw < C) return fail(ADCDIFF_E_BADARG, "groupnorm_silu: ldraw=%d < C=%d", ldraw, C);
     if (out_dtype == ADCDIFF_F32)
         return gn_launch<float>(x, ldx, M, C, groups, gamma, beta, eps, reinterpret_cast<float*>(out), ldo,
@@ -324,6 +347,7 @@ extern "C" int adcdiff_ddpm_step(const float* x, int ldx, const float* eps, int 
         return fail(ADCDIFF_E_BADARG, "ddpm_step: B=%d D=%d (multiple of 4), pointers 16-byte aligned, ld >= D", B, D);
     const long total4 = (long)B * (D / 4);
     const dim3 grid((unsigned)((total4 + 255) / 256));
+    TimingScope ts(ADCDIFF_KIND_UPDATE, B, D, 0, 0.0, (double)B * D * (noise ? 16.0 : 12.0), as_stream(stream));
     if (noise)
         hipLaunchKernelGGL((ddpm_step_kernel<true>), grid, dim3(256), 0, as_stream(stream), x, ldx, eps, lde, noise, ldn, out, ldo,
                            total4, D / 4, coef, seed, step, row_offset);
@@ -365,4 +389,40 @@ extern "C" int adcdiff_q_sample(const float* x0, int ldx, const int64_t* t, cons
         hipLaunchKernelGGL((q_sample_kernel<false>), grid, dim3(256), 0, as_stream(stream), x0, ldx, t, sqrt_ac, sqrt_one_minus_ac,
                            noise, ldn, out, ldo, noise_out, ldno, total4, D / 4, seed, step, row_offset);
     return check_launch("q_sample");
+}
+
+extern "C" int adcdiff_timing_begin(int max_records) {
+    if (max_records <= 0) return fail(ADCDIFF_E_BADARG, "timing_begin: max_records=%d", max_records);
+    if (g_timing.on) return fail(ADCDIFF_E_BADARG, "timing_begin: already active");
+    if (g_timing.cap < max_records) {
+        for (int i = 0; i < 2 * g_timing.cap; ++i) (void)hipEventDestroy(g_timing.ev[i]);
+        delete[] g_timing.ev;
+        delete[] g_timing.rec;
+        g_timing.ev = new hipEvent_t[2 * (size_t)max_records];
+        g_timing.rec = new adcdiff_timing_record[max_records];
+        g_timing.cap = 0;
+        for (int i = 0; i < 2 * max_records; ++i) {
+            hipError_t e = hipEventCreate(&g_timing.ev[i]);
+            if (e != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "timing_begin: hipEventCreate: %s", hipGetErrorString(e));
+        }
+        g_timing.cap = max_records;
+    }
+    g_timing.used = 0;
+    g_timing.on = true;
+    return ADCDIFF_OK;
+}
+
+extern "C" int adcdiff_timing_end(adcdiff_timing_record* out, int capacity, int* count) {
+    if (!g_timing.on) return fail(ADCDIFF_E_BADARG, "timing_end: not active");
+    g_timing.on = false;
+    if (!out || !count) return fail(ADCDIFF_E_BADARG, "timing_end: null output");
+    int n = g_timing.used < capacity ? g_timing.used : capacity;
+    for (int i = 0; i < n; ++i) {
+        hipError_t e = hipEventSynchronize(g_timing.ev[2 * i + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&g_timing.rec[i].ms, g_timing.ev[2 * i], g_timing.ev[2 * i + 1]);
+        if (e != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "timing_end: %s", hipGetErrorString(e));
+        out[i] = g_timing.rec[i];
+    }
+    *count = n;
+    return ADCDIFF_OK;
 }

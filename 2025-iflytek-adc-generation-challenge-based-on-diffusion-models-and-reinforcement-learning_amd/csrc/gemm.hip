@@ -6,8 +6,9 @@
 // operands) or v_mfma_f32_32x32x2_f32 (float32 operands, exact f32 fma chain), float32 accumulate.
 // Both operand tiles are staged in LDS as rows of 128 bytes (64 bf16 / 32 f32 of K), eight 16-byte
 // chunks per row, chunk index XOR-swizzled with (row >> 1) & 7 so that the 16-lane groups of a
-// ds_read_b128 hit sixteen different 16-byte slots of the 256-byte bank row.  Global loads for tile
-// t+1 are issued before the MFMAs of tile t and written to the other LDS stage after them.
+// ds_read_b128 hit sixteen different 16-byte slots of the 256-byte bank row.  Tiles go global -> LDS
+// directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write); one LDS stage of 32 KiB per
+// workgroup, two barriers per K step, latency hidden by 3-4 resident workgroups per CU.
 // Workgroup ids are remapped so that the N-tiles of one M-tile run on one XCD (they share the A rows
 // in that XCD's L2).
 #include "common.h"
@@ -34,16 +35,29 @@ struct GemmParams {
     int ldo_bf16;
 };
 
+// LDS-DMA copy of 16 bytes per lane: the wave's 64 lanes fill 1 KiB starting at the wave-uniform `lds`.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
+    constexpr bool BF = sizeof(T) == 2;
     constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
     constexpr int BK = 8 * EPC;                // K elements per 128-byte LDS row
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave
-    constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+    constexpr int A_BYTES = BM * 128;
+    constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile (2 x 2 waves)
+    constexpr int TS = BF ? 16 : 32;           // MFMA tile edge: 16x16x32 bf16 / 32x32x2 f32
+    constexpr int TM = WTM / TS, TN = WTN / TS;
+    constexpr int NACC = BF ? 4 : 16;
+    constexpr int A_PIECES = BM / 8 / 4, B_PIECES = BN / 8 / 4;   // 1 KiB pieces (8 rows) per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sa = smem;
+    char* const sb = smem + A_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
     int bid = blockIdx.x;
@@ -51,115 +65,154 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
 
-    uint4 ra[A_CH], rb[B_CH];
-    const char* Wb = reinterpret_cast<const char*>(p.W);
-    const long ldw_b = (long)p.ldw * (long)sizeof(T);
+    // staging: lane l of piece q fills LDS row 8q + (l >> 3), chunk position l & 7, which holds the logical
+    // chunk (l & 7) ^ ((row >> 1) & 7): the swizzle is applied on the SOURCE address, the LDS image stays
+    // lane-linear as the LDS-DMA requires.
+    const int prow = lane >> 3;
+    long a_off[A_PIECES], b_off[B_PIECES];
+    int a_row[A_PIECES];
+#pragma unroll
+    for (int j = 0; j < A_PIECES; ++j) {
+        const int row = 8 * (wave * A_PIECES + j) + prow;
+        a_row[j] = m0 + row;
+        a_off[j] = (long)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PIECES; ++j) {
+        const int row = 8 * (wave * B_PIECES + j) + prow;
+        b_off[j] = (long)(n0 + row) * p.ldw * (long)sizeof(T) + (long)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+    const char* const Wb = reinterpret_cast<const char*>(p.W);
 
-    auto gload = [&](int t) {
-        int s = 0, tt = t;
-        if (tt >= p.ktiles[0]) { tt -= p.ktiles[0]; s = 1; if (tt >= p.ktiles[1]) { tt -= p.ktiles[1]; s = 2; } }
-        const char* Ab = reinterpret_cast<const char*>(s == 0 ? p.A[0] : (s == 1 ? p.A[1] : p.A[2]));
-        const long lda_b = (long)(s == 0 ? p.lda[0] : (s == 1 ? p.lda[1] : p.lda[2])) * (long)sizeof(T);
-#pragma unroll
-        for (int j = 0; j < A_CH; ++j) {
-            const int q = tid + 256 * j, row = q >> 3, c = q & 7;
-            ra[j] = *reinterpret_cast<const uint4*>(Ab + (long)(m0 + row) * lda_b + ((long)tt * BK + c * EPC) * (long)sizeof(T));
-        }
-#pragma unroll
-        for (int j = 0; j < B_CH; ++j) {
-            const int q = tid + 256 * j, row = q >> 3, c = q & 7;
-            rb[j] = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + row) * ldw_b + ((long)t * BK + c * EPC) * (long)sizeof(T));
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* sa = smem + buf * STAGE;
-        char* sb = sa + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < A_CH; ++j) {
-            const int q = tid + 256 * j, row = q >> 3, c = q & 7;
-            *reinterpret_cast<uint4*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = ra[j];
-        }
-#pragma unroll
-        for (int j = 0; j < B_CH; ++j) {
-            const int q = tid + 256 * j, row = q >> 3, c = q & 7;
-            *reinterpret_cast<uint4*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = rb[j];
-        }
-    };
-
-    f32x16 acc[TM][TN];
+    typedef float acc_t __attribute__((ext_vector_type(NACC)));
+    acc_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < NACC; ++r) acc[i][j][r] = 0.0f;
 
-    const int lrow = lane & 31, lhalf = lane >> 5;
-    auto compute = [&](int buf) {
-        const char* sa = smem + buf * STAGE;
-        const char* sb = sa + A_BYTES;
+    // fragment addressing: bf16 16x16x32 -- lane holds row (l & 15), k chunk (l >> 4) of each 32-wide k step;
+    // f32 32x32x2 -- lane holds row (l & 31) and four consecutive k of chunk 2s + (l >> 5); A and B use the
+    // same k permutation, which is all the contraction needs.
+    const int frow = BF ? (lane & 15) : (lane & 31);
+    const int fchunk = BF ? (lane >> 4) : (lane >> 5);
+
+    int seg = 0, tt = 0;
+    const char* Ab = reinterpret_cast<const char*>(p.A[0]);
+    long lda_b = (long)p.lda[0] * (long)sizeof(T);
+    for (int t = 0; t < p.nt_total; ++t, ++tt) {
+        if (tt == p.ktiles[seg]) {   // next K segment (wave-uniform)
+            ++seg; tt = 0;
+            if (tt == p.ktiles[seg]) { ++seg; }
+            Ab = reinterpret_cast<const char*>(seg == 1 ? p.A[1] : p.A[2]);
+            lda_b = (long)(seg == 1 ? p.lda[1] : p.lda[2]) * (long)sizeof(T);
+        }
+        const long ka = (long)tt * 128, kw = (long)t * 128;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int c = 2 * s + lhalf;
-            uint4 af[TM], bf[TN];
+        for (int j = 0; j < A_PIECES; ++j)
+            glds16(Ab + (long)a_row[j] * lda_b + ka + a_off[j], sa + (wave * A_PIECES + j) * 1024);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * (BM / 2) + i * 32 + lrow;
-                af[i] = *reinterpret_cast<const uint4*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
+        for (int j = 0; j < B_PIECES; ++j)
+            glds16(Wb + b_off[j] + kw, sb + (wave * B_PIECES + j) * 1024);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (BF) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn * (BN / 2) + j * 32 + lrow;
-                bf[j] = *reinterpret_cast<const uint4*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
+            for (int ks = 0; ks < 2; ++ks) {
+                const int c = 4 * ks + fchunk;
+                uint4 af[TM], bfr[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * WTM + i * 16 + frow;
+                    af[i] = *reinterpret_cast<const uint4*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if constexpr (sizeof(T) == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
-                    } else {
-                        const f32x4 a4 = __builtin_bit_cast(f32x4, af[i]), b4 = __builtin_bit_cast(f32x4, bf[j]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i][j], 0, 0, 0);
-                    }
+                    const int row = wn * WTN + j * 16 + frow;
+                    bfr[j] = *reinterpret_cast<const uint4*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
                 }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                            __builtin_bit_cast(bf16x8, bfr[j]), acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = 2 * ks + fchunk;
+                f32x4 af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * WTM + i * 32 + frow;
+                    af[i] = *reinterpret_cast<const f32x4*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = wn * WTN + j * 32 + frow;
+                    bfr[j] = *reinterpret_cast<const f32x4*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+            }
         }
-    };
-
-    const int nt = p.nt_total;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) gload(t + 1);
-        compute(t & 1);
-        if (t + 1 < nt) lstore((t + 1) & 1);
         __syncthreads();
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // epilogue.  C/D layouts: 16x16 -- col = l & 15, row = 4 * (l >> 4) + r; 32x32 -- col = l & 31,
+    // row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).  Optional inputs are read through always-valid pointers
+    // (W stands in for an absent one, with stride 0) and masked by selects, so the loads of a row are issued
+    // together instead of one wave-uniform branch and one wait per element.
+    const int ccol = BF ? (lane & 15) : (lane & 31);
+    const int crow0 = BF ? 4 * (lane >> 4) : 4 * (lane >> 5);
+    const bool has_bias = p.bias != nullptr, has_rb = p.rowbias != nullptr, has_idx = p.rowbias_idx != nullptr;
+    const bool has_res = p.residual != nullptr, act = p.act == 1;
+    const float* const dummy = reinterpret_cast<const float*>(p.W);
+    const float* const biasp = has_bias ? p.bias : dummy;
+    const float* const rbp = has_rb ? p.rowbias : dummy;
+    const long ldrb = has_rb ? p.ldrb : 0;
+    const float* const resp = has_res ? p.residual : dummy;
+    const long ldr = has_res ? p.ldr : 0;
+    float bcol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const float b = biasp[n0 + wn * WTN + j * TS + ccol];
+        bcol[j] = has_bias ? b : 0.0f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 32 + lrow;
-            const float bcol = p.bias ? p.bias[col] : 0.0f;
+        for (int r = 0; r < NACC; ++r) {
+            const int row = m0 + wm * WTM + i * TS + crow0 + (BF ? r : (r & 3) + 8 * (r >> 2));
+            if (row < p.m_valid) {
+                const long ridx = has_idx ? (long)p.rowbias_idx[row] : (long)row;
+                const float* const rb = rbp + ridx * ldrb;
+                const float* const rs = resp + (long)row * ldr;
+                float add0[TN], add1[TN];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                if (row >= p.m_valid) continue;
-                float v = acc[i][j][r] + bcol;
-                if (p.rowbias) {
-                    const long rr = p.rowbias_idx ? (long)p.rowbias_idx[row] : (long)row;
-                    v += p.rowbias[rr * p.ldrb + col];
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * WTN + j * TS + ccol;
+                    add0[j] = rb[col];
+                    add1[j] = rs[col];
                 }
-                if (p.residual) v += p.residual[(long)row * p.ldr + col];
-                if (p.act == 1) v = silu_f(v);
-                if (p.out_f32) p.out_f32[(long)row * p.ldo_f32 + col] = v;
-                if (p.out_bf16) p.out_bf16[(long)row * p.ldo_bf16 + col] = (bf16_t)v;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * WTN + j * TS + ccol;
+                    float v = acc[i][j][r] + bcol[j];
+                    v += has_rb ? add0[j] : 0.0f;
+                    v += has_res ? add1[j] : 0.0f;
+                    if (act) v = silu_f(v);   // wave-uniform
+                    if (p.out_f32) p.out_f32[(long)row * p.ldo_f32 + col] = v;
+                    if (p.out_bf16) p.out_bf16[(long)row * p.ldo_bf16 + col] = (bf16_t)v;
+                }
             }
         }
     }
@@ -167,7 +220,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
 
 template <typename T, int BM, int BN>
 static int launch(const GemmParams& p, hipStream_t stream) {
-    constexpr int smem = 2 * (BM + BN) * 128;
+    constexpr int smem = (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN>),
@@ -216,6 +269,11 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     p.residual = a.residual; p.ldr = a.ldr; p.act = a.act;
     p.out_f32 = a.out_f32; p.ldo_f32 = a.ldo_f32;
     p.out_bf16 = reinterpret_cast<bf16_t*>(a.out_bf16); p.ldo_bf16 = a.ldo_bf16;
+    const double esz = esize;
+    TimingScope ts(a.dtype == ADCDIFF_BF16 ? ADCDIFF_KIND_GEMM_BF16 : ADCDIFF_KIND_GEMM_F32, a.M, a.N, ktot,
+                   2.0 * a.M * a.N * ktot, esz * ((double)a.M * ktot + (double)a.N * ktot) + (double)a.M * a.N * (a.out_f32 ? 4.0 : 0.0) +
+                       (double)a.M * a.N * (a.out_bf16 ? 2.0 : 0.0) + (a.residual ? 4.0 * a.M * a.N : 0.0),
+                   stream);
     const bool wide = (a.N % 128 == 0);
     if (a.dtype == ADCDIFF_BF16) return wide ? launch<bf16_t, 128, 128>(p, stream) : launch<bf16_t, 128, 64>(p, stream);
     return wide ? launch<float, 128, 128>(p, stream) : launch<float, 128, 64>(p, stream);

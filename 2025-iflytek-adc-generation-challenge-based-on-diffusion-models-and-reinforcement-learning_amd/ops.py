@@ -146,3 +146,22 @@ def q_sample(x0, t, sqrt_ac, sqrt_1mac, noise=None, seed=0, step=0, row_offset=0
                                noise.stride(0) if noise is not None else 0, _ptr(out), D, _ptr(nz_out), D, B, D, seed, step,
                                row_offset, _stream()))
     return (out, nz_out) if return_noise else out
+
+
+class timing:
+    """Context manager over adcdiff_timing_begin/_end: ``with ops.timing(4096) as t: ...; t.records``."""
+
+    def __init__(self, max_records):
+        self.max_records = max_records
+        self.records = []
+
+    def __enter__(self):
+        check(_lib.load().adcdiff_timing_begin(self.max_records))
+        return self
+
+    def __exit__(self, *exc):
+        buf = (_lib.TimingRecord * self.max_records)()
+        n = C.c_int(0)
+        check(_lib.load().adcdiff_timing_end(buf, self.max_records, C.byref(n)))
+        self.records = [dict(kind=r.kind, M=r.M, N=r.N, K=r.K, ms=r.ms, flops=r.flops, bytes=r.bytes) for r in buf[:n.value]]
+        return False

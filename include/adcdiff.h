@@ -175,6 +175,24 @@ int adcdiff_ddim_sample_loop(adcdiff_unet* net, float* x, int ldx, int B, const 
                              long long noise_step_stride, uint64_t seed, uint64_t row_offset, void* workspace,
                              size_t workspace_bytes, adcdiff_stream_t stream);
 
+/* ------------------------------------------------------------------ measurement ------ */
+
+/* Per-launch timing for benchmarks; no counterpart in the reference.  Between adcdiff_timing_begin and
+ * adcdiff_timing_end every GEMM, GroupNorm+SiLU and schedule-update launch made through this library is
+ * bracketed by a pair of hipEvents on the stream it is launched on (up to max_records launches; later
+ * ones are not recorded).  adcdiff_timing_end synchronises those events and returns one record per
+ * launch.  Not thread safe; not for use under graph capture. */
+enum { ADCDIFF_KIND_GEMM_F32 = 0, ADCDIFF_KIND_GEMM_BF16 = 1, ADCDIFF_KIND_GROUPNORM = 2, ADCDIFF_KIND_UPDATE = 3 };
+typedef struct adcdiff_timing_record {
+    int kind;
+    int M, N, K;        /* GEMM: rows, outputs, total K; others: rows, columns, 0 */
+    float ms;           /* device time between the two events */
+    double flops;       /* 2*M*N*K for a GEMM, 0 otherwise */
+    double bytes;       /* algorithmic HBM bytes of the launch (operands read once + outputs written once) */
+} adcdiff_timing_record;
+int adcdiff_timing_begin(int max_records);
+int adcdiff_timing_end(adcdiff_timing_record* out, int capacity, int* count);
+
 #ifdef __cplusplus
 }
 #endif
