@@ -11,12 +11,16 @@ STREAM_XT, STREAM_STEP, STREAM_QNOISE, STREAM_TDRAW = 1, 2, 3, 4
 c_fp = C.c_void_p   # device pointers travel as integers
 
 
+class GnOut(C.Structure):
+    _fields_ = [("gamma", c_fp), ("beta", c_fp), ("out", c_fp), ("ldo", C.c_int), ("group_size", C.c_int)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("m_valid", C.c_int), ("nseg", C.c_int),
                 ("A", c_fp * 3), ("lda", C.c_int * 3), ("K", C.c_int * 3), ("W", c_fp), ("ldw", C.c_int),
                 ("bias", c_fp), ("rowbias", c_fp), ("ldrb", C.c_longlong), ("rowbias_idx", c_fp),
                 ("residual", c_fp), ("ldr", C.c_int), ("act", C.c_int), ("out_f32", c_fp), ("ldo_f32", C.c_int),
-                ("out_bf16", c_fp), ("ldo_bf16", C.c_int)]
+                ("out_op", c_fp), ("ldo_op", C.c_int), ("n_gn", C.c_int), ("gn", GnOut * 2), ("gn_eps", C.c_float)]
 
 
 class DdpmCoef(C.Structure):

@@ -3,14 +3,18 @@
 // weights and timestep tables live in the caller's arena, activations in the caller's workspace, both
 // carved by a bump allocator whose dry run gives the sizes reported to the caller.
 //
-// Per ResidualBlock (diffusion_model.py:875-907), with the input given as one or two parts (the
-// decoder's cat([h, skip]) is never materialised un-normalised):
-//   a1 = SiLU(GroupNorm1(parts))                     groupnorm_silu per part (groups never straddle parts)
-//   h1 = [a1 | s] * [W1 | Wtp]^T + b1 (+ table[t])   one GEMM; the time_proj term is a per-timestep table
-//                                                    row when unconditional, an extra K segment
-//                                                    s = SiLU(t_emb + c_emb) when a condition is given
-//   a2 = SiLU(GroupNorm2(h1))
-//   o  = [a2 | parts] * [W2 | Wres]^T + b2 + bres    one GEMM (Identity residual: + x in the epilogue)
+// Per ResidualBlock (diffusion_model.py:875-907) two GEMM launches and nothing else; every GroupNorm+SiLU
+// is applied by the GEMM that PRODUCES its input, from the float32 accumulators, so each tensor is
+// written once in the forms its consumers need and never re-read to be normalised:
+//   GEMM1: a2 = SiLU(GroupNorm2([n_in | s] * [W1 | Wtp]^T + b1 (+ table[t])))
+//          n_in = the already normalised input part(s) (cat([h, skip]) is two K segments, never a copy);
+//          the time_proj term is a per-timestep table row when unconditional and an extra K segment
+//          s = SiLU(t_emb + c_emb) when a condition makes it row dependent
+//   GEMM2: o = [a2 | raw_in] * [W2 | Wres]^T + b2 + bres   (Identity residual: + raw_in in the epilogue)
+//          stored as raw_o (operand type: the next residual operand) and as SiLU(GroupNorm(o)) under the
+//          norm1 of the next block and, for encoder outputs, under the decoder's norm1 slice of the skip
+// Dimensions whose GroupNorm groups are not powers of two in 4..128 take the unfused path (float32 layer
+// outputs, stand-alone groupnorm_silu kernels), which has no such restriction.
 #include <cstring>
 #include <new>
 
@@ -53,6 +57,7 @@ struct BlockPlan {
     int g1, g2, tb_off, ldw1, ldw2;
     void *w1cat, *w2cat;
     float *bias1, *bias1_cond, *bias2;
+    int gs1, gs2;   // channels per GroupNorm group of norm1 (over the whole concatenated input) and norm2
 };
 
 }  // namespace adcdiff
@@ -67,6 +72,7 @@ struct adcdiff_unet {
     void *w_out, *w_c0, *w_c2;
     size_t arena_used;
     bool packed;
+    bool fused;     // every GroupNorm can be applied in a producing GEMM's epilogue
 };
 
 static int plan_dims(adcdiff_unet* n, int input_dim, int hidden_dim, int output_dim, int num_timesteps, int dtype) {
@@ -95,8 +101,17 @@ static int plan_dims(adcdiff_unet* n, int input_dim, int hidden_dim, int output_
         b.tb_off = off; off += b.cout;
         b.ldw1 = b.cin + h;
         b.ldw2 = b.cout + (b.has_res ? b.cin : 0);
+        b.gs1 = gs; b.gs2 = b.cout / b.g2;
     }
     n->sumN = off;
+    auto fusable = [](int gs, int width) { return gs >= 4 && gs <= (width % 128 == 0 ? 128 : 64) && (gs & (gs - 1)) == 0; };
+    n->fused = fusable(hidden_dim / num_groups(hidden_dim), hidden_dim);   // output_norm, applied by decoder.3's GEMM
+    for (int i = 0; i < 10; ++i) {
+        const BlockPlan& b = n->blk[i];
+        n->fused = n->fused && fusable(b.gs2, b.cout);
+        if (i > 0) n->fused = n->fused && fusable(b.gs1, n->blk[i - 1].cout);           // applied by the previous block
+        if (i >= 6) n->fused = n->fused && fusable(b.gs1, n->blk[9 - i].cout);          // and by the skip's encoder block
+    }
     return ADCDIFF_OK;
 }
 
@@ -234,7 +249,7 @@ struct Part {
 };
 
 // One denoiser forward.  With dry = true nothing is launched and only the bump offset advances.
-int forward_impl(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform, const float* cemb,
+int forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform, const float* cemb,
                  int ldce, float* eps, int lde, Bump& ws, bool dry, hipStream_t st) {
     const int Bp = (int)round_up((size_t)B, 128);
     const size_t e = (size_t)n->esz;
@@ -266,7 +281,7 @@ int forward_impl(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t*
         int col = 0;
         for (int k = 0; k < ncur; ++k) {
             void* raw = nullptr;
-            if (b.has_res && !cur[k].raw) raw = ws.take((size_t)Bp * cur[k].C * e);
+            if (!cur[k].raw) raw = ws.take((size_t)Bp * cur[k].C * e);   // residual_proj operand or Identity residual
             if (!dry)
                 TRY(groupnorm_silu(cur[k].f32, cur[k].ld, B, cur[k].C, cur[k].C / gs, q.norm1_w + col, q.norm1_b + col, 1e-5f, dt,
                                    a1 + (size_t)col * e, b.cin, raw, cur[k].C, st));
@@ -305,7 +320,7 @@ int forward_impl(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t*
                     ++g.nseg;
                 }
             } else {
-                g.residual = cur[0].f32; g.ldr = cur[0].ld;
+                g.residual = cur[0].raw; g.ldr = cur[0].C;
             }
             g.out_f32 = o; g.ldo_f32 = b.cout;
             TRY(gemm_dispatch(g, st));
@@ -326,6 +341,108 @@ int forward_impl(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t*
         TRY(gemm_dispatch(g, st));
     }
     return ADCDIFF_OK;
+}
+
+// The fused path (see the header comment).  Activations are kept only in the operand type.
+struct Act {
+    const void* raw;    // layer output o in the operand type, [Bp, C]
+    const void* n_next; // SiLU(GroupNorm(o)) under the next block's norm1 (or output_norm)
+    const void* n_skip; // SiLU(GroupNorm(o)) under the consuming decoder's norm1 slice (encoder outputs only)
+    int C;
+};
+
+int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform, const float* cemb,
+                  int ldce, float* eps, int lde, Bump& ws, bool dry, hipStream_t st) {
+    const int Bp = (int)round_up((size_t)B, 128);
+    const size_t e = (size_t)n->esz;
+    const int H = n->H, dt = n->dtype;
+    const adcdiff_unet_params& p = n->prm;
+    const bool cond = cemb != nullptr;
+
+    const void* s_op = nullptr;
+    if (cond || dry) {
+        void* s = ws.take((size_t)Bp * H * e);
+        if (!dry) TRY(temb_silu(n->te_table, H, t_rows, t_uniform, cemb, ldce, dt, s, H, B, H, st));
+        s_op = s;
+    }
+    // the latent enters through the one stand-alone GroupNorm of the step: encoder.0's norm1 (diffusion_model.py:888-889)
+    Act in;
+    {
+        const BlockPlan& b0 = n->blk[0];
+        void* nrm = ws.take((size_t)Bp * n->D * e);
+        void* raw = ws.take((size_t)Bp * n->D * e);
+        if (!dry) TRY(groupnorm_silu(x, ldx, B, n->D, b0.g1, p.blocks[0].norm1_w, p.blocks[0].norm1_b, 1e-5f, dt, nrm, n->D, raw, n->D, st));
+        in = Act{raw, nrm, nullptr, n->D};
+    }
+    Act outs[10];
+    for (int i = 0; i < 10; ++i) {
+        const BlockPlan& b = n->blk[i];
+        const adcdiff_block_params& q = p.blocks[i];
+        const Act& c0 = i == 0 ? in : outs[i - 1];
+        const Act* c1 = i >= 6 ? &outs[9 - i] : nullptr;   // decoder skip = encoder output 3, 2, 1, 0 (diffusion_model.py:781-782)
+        void* a2 = ws.take((size_t)Bp * b.cout * e);
+        if (!dry) {
+            adcdiff_gemm_args g = gemm_args(dt, Bp, B, b.cout);
+            g.nseg = 0;
+            g.A[g.nseg] = c0.n_next; g.lda[g.nseg] = c0.C; g.K[g.nseg] = c0.C; ++g.nseg;
+            if (c1) { g.A[g.nseg] = c1->n_skip; g.lda[g.nseg] = c1->C; g.K[g.nseg] = c1->C; ++g.nseg; }
+            g.W = b.w1cat; g.ldw = b.ldw1;
+            if (cond) {
+                g.A[g.nseg] = s_op; g.lda[g.nseg] = H; g.K[g.nseg] = H; ++g.nseg;
+                g.bias = b.bias1_cond;
+            } else {
+                g.bias = b.bias1;
+                if (t_rows) { g.rowbias = n->tb_table + b.tb_off; g.ldrb = n->sumN; g.rowbias_idx = t_rows; }
+                else { g.rowbias = n->tb_table + (size_t)t_uniform * n->sumN + b.tb_off; g.ldrb = 0; }
+            }
+            g.n_gn = 1; g.gn_eps = 1e-5f;
+            g.gn[0] = adcdiff_gn_out{q.norm2_w, q.norm2_b, a2, b.cout, b.gs2};
+            TRY(gemm_dispatch(g, st));
+        }
+        // second GEMM: linear2 + residual, emitting what the consumers of this block's output read
+        void* raw = i < 9 ? ws.take((size_t)Bp * b.cout * e) : nullptr;
+        void* n_next = ws.take((size_t)Bp * b.cout * e);
+        void* n_skip = i <= 3 ? ws.take((size_t)Bp * b.cout * e) : nullptr;
+        if (!dry) {
+            adcdiff_gemm_args g = gemm_args(dt, Bp, B, b.cout);
+            g.nseg = 1; g.A[0] = a2; g.lda[0] = b.cout; g.K[0] = b.cout;
+            g.W = b.w2cat; g.ldw = b.ldw2; g.bias = b.bias2;
+            if (b.has_res) {
+                g.A[g.nseg] = c0.raw; g.lda[g.nseg] = c0.C; g.K[g.nseg] = c0.C; ++g.nseg;
+                if (c1) { g.A[g.nseg] = c1->raw; g.lda[g.nseg] = c1->C; g.K[g.nseg] = c1->C; ++g.nseg; }
+            } else {
+                g.residual = c0.raw; g.ldr = c0.C;
+            }
+            g.out_op = raw; g.ldo_op = b.cout;
+            g.gn_eps = 1e-5f;
+            if (i < 9) {
+                const BlockPlan& nb = n->blk[i + 1];
+                g.gn[g.n_gn++] = adcdiff_gn_out{p.blocks[i + 1].norm1_w, p.blocks[i + 1].norm1_b, n_next, b.cout, nb.gs1};
+            } else {
+                g.gn[g.n_gn++] = adcdiff_gn_out{p.out_norm_w, p.out_norm_b, n_next, b.cout, H / num_groups(H)};
+            }
+            if (i <= 3) {
+                const BlockPlan& db = n->blk[9 - i];
+                g.gn[g.n_gn++] = adcdiff_gn_out{p.blocks[9 - i].norm1_w + db.part_c[0], p.blocks[9 - i].norm1_b + db.part_c[0], n_skip,
+                                                b.cout, db.gs1};
+            }
+            TRY(gemm_dispatch(g, st));
+        }
+        outs[i] = Act{raw, n_next, n_skip, b.cout};
+    }
+    if (!dry) {   // output head (diffusion_model.py:786-788): its GroupNorm + SiLU was applied by decoder.3's GEMM
+        adcdiff_gemm_args g = gemm_args(dt, Bp, B, n->O);
+        g.nseg = 1; g.A[0] = outs[9].n_next; g.lda[0] = H; g.K[0] = H; g.W = n->w_out; g.ldw = H; g.bias = p.out_b;
+        g.out_f32 = eps; g.ldo_f32 = lde;
+        TRY(gemm_dispatch(g, st));
+    }
+    return ADCDIFF_OK;
+}
+
+int forward_impl(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform, const float* cemb,
+                 int ldce, float* eps, int lde, Bump& ws, bool dry, hipStream_t st) {
+    return n->fused ? forward_fused(n, x, ldx, B, t_rows, t_uniform, cemb, ldce, eps, lde, ws, dry, st)
+                    : forward_unfused(n, x, ldx, B, t_rows, t_uniform, cemb, ldce, eps, lde, ws, dry, st);
 }
 
 size_t forward_bytes(adcdiff_unet* n, int B) {
@@ -366,7 +483,7 @@ extern "C" int adcdiff_unet_condition_embed(adcdiff_unet* n, const float* cond, 
     TRY(cast_pack(cond, ldc, n->dtype, c_op, n->D, 0, B, n->D, st));
     adcdiff_gemm_args g = gemm_args(n->dtype, Bp, B, n->H);
     g.nseg = 1; g.A[0] = c_op; g.lda[0] = n->D; g.K[0] = n->D; g.W = n->w_c0; g.ldw = n->D; g.bias = n->prm.cond0_b; g.act = 1;
-    if (n->dtype == ADCDIFF_BF16) { g.out_bf16 = hid; g.ldo_bf16 = n->H; } else { g.out_f32 = (float*)hid; g.ldo_f32 = n->H; }
+    g.out_op = hid; g.ldo_op = n->H;
     TRY(gemm_dispatch(g, st));
     g = gemm_args(n->dtype, Bp, B, n->H);
     g.nseg = 1; g.A[0] = hid; g.lda[0] = n->H; g.K[0] = n->H; g.W = n->w_c2; g.ldw = n->H; g.bias = n->prm.cond2_b;

@@ -46,13 +46,16 @@ def _operand(x, code):
     return buf
 
 
-def gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, act=0, out_bf16=False, m_valid=None,
-         dtype="fp32"):
-    """out = act([A0|A1|A2] @ w.T + bias + rowbias + residual) through adcdiff_gemm.
+def gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, act=0, out_f32=True, out_op=False, gn=(),
+         m_valid=None, dtype="fp32", eps=1e-5):
+    """adcdiff_gemm: v = [A0|A1|A2] @ w.T + bias + rowbias + residual.
 
-    a_list: operand tensors [M, K_s] (M a multiple of 128) already in the operand dtype; w [N, sum K_s]."""
+    a_list: operand tensors [M, K_s] (M a multiple of 128) already in the operand dtype; w [N, sum K_s]; residual in the
+    operand dtype; gn: up to two (gamma, beta, group_size) for fused SiLU(GroupNorm(v)) outputs in the operand dtype.
+    Returns the requested outputs in the order (v float32, v operand type, gn outputs...), a single tensor if only one."""
     lib = _lib.load()
     code = dtype_code(dtype)
+    td = torch.bfloat16 if code == BF16 else torch.float32
     _need_gpu(w, *a_list)
     M = a_list[0].shape[0]
     N = w.shape[0]
@@ -70,15 +73,26 @@ def gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, ac
     if residual is not None:
         args.residual, args.ldr = residual.data_ptr(), residual.stride(0)
     args.act = act
-    rows = M
-    if out_bf16:
-        out = torch.empty((rows, N), device=w.device, dtype=torch.bfloat16)
-        args.out_bf16, args.ldo_bf16 = out.data_ptr(), N
-    else:
-        out = torch.empty((rows, N), device=w.device, dtype=torch.float32)
-        args.out_f32, args.ldo_f32 = out.data_ptr(), N
+    outs = []
+    if out_f32:
+        o = torch.empty((M, N), device=w.device, dtype=torch.float32)
+        args.out_f32, args.ldo_f32 = o.data_ptr(), N
+        outs.append(o)
+    if out_op:
+        o = torch.empty((M, N), device=w.device, dtype=td)
+        args.out_op, args.ldo_op = o.data_ptr(), N
+        outs.append(o)
+    args.n_gn = len(gn)
+    args.gn_eps = eps
+    keep = []
+    for i, (gamma, beta, gs) in enumerate(gn):
+        o = torch.empty((M, N), device=w.device, dtype=td)
+        keep += [gamma, beta]
+        args.gn[i].gamma, args.gn[i].beta, args.gn[i].out, args.gn[i].ldo, args.gn[i].group_size = \
+            gamma.data_ptr(), beta.data_ptr(), o.data_ptr(), N, int(gs)
+        outs.append(o)
     check(lib.adcdiff_gemm(C.byref(args), _stream()))
-    return out
+    return outs[0] if len(outs) == 1 else tuple(outs)
 
 
 def linear(x, weight, bias, act=0, dtype="fp32"):

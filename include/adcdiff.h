@@ -44,16 +44,29 @@ const char* adcdiff_last_error(void);
 
 /* ------------------------------------------------------------------ single kernels ---- */
 
-/* out = act( [A0 | A1 | A2] * W^T + bias + rowbias + residual ): nn.Linear (diffusion_model.py:852-853,
- * 799-800, 695-697, 733, 871) with the K dimension split over up to three A operands, which is how
+/* v = [A0 | A1 | A2] * W^T + bias + rowbias + residual: nn.Linear (diffusion_model.py:852-853, 799-800,
+ * 695-697, 733, 871) with the K dimension split over up to three A operands, which is how
  * torch.cat([h, skip]) (:782) and linear2 + residual_proj (:885, :899, :907) are consumed without
  * materialising the concatenation.  W is [N, K0+K1+K2] row-major (nn.Linear layout).
+ * Outputs (any subset): v in float32, v in the operand type (the next block's residual_proj operand),
+ * and up to two SiLU(GroupNorm(v)) in the operand type -- the GroupNorm + SiLU that the CONSUMER of this
+ * layer applies first (norm2 before linear2 :896-897, the next block's norm1 :888-889, the decoder's
+ * norm1 over its skip half, output_norm :786-787), computed here from the float32 accumulators so the
+ * layer output is never re-read to be normalised.
  * Requirements: M % 128 == 0, N % 64 == 0, every K_s a multiple of 32 (F32) / 64 (BF16), all pointers
- * 16-byte aligned, lda * sizeof(operand) % 16 == 0. */
+ * 16-byte aligned, every leading dimension * element size a multiple of 16 bytes. */
+typedef struct adcdiff_gn_out {
+    const float* gamma;        /* GroupNorm weight for this GEMM's N columns */
+    const float* beta;         /* GroupNorm bias */
+    void* out;                 /* [M, ldo] in the operand type */
+    int ldo;
+    int group_size;            /* channels per group: a power of two, 4..128 (4..64 when N % 128 != 0), dividing N */
+} adcdiff_gn_out;
+
 typedef struct adcdiff_gemm_args {
-    int dtype;                 /* operand type of A and W: ADCDIFF_F32 / ADCDIFF_BF16 */
+    int dtype;                 /* operand type of A, W, residual, out_op and gn outputs: ADCDIFF_F32 / ADCDIFF_BF16 */
     int M, N;
-    int m_valid;               /* rows >= m_valid are computed but not read from rowbias_idx/residual nor stored; 0 = M */
+    int m_valid;               /* rows >= m_valid are computed but read no per-row side input and store nothing; 0 = M */
     int nseg;                  /* 1..3 */
     const void* A[3];
     int lda[3];
@@ -66,13 +79,16 @@ typedef struct adcdiff_gemm_args {
                                   ldrb == 0 broadcasts one row (the hoisted time_proj term, :893) */
     long long ldrb;
     const int64_t* rowbias_idx;/* [M] timestep per row, or NULL */
-    const float* residual;     /* float32 [M, N] added to the result (Identity residual, :873), or NULL */
+    const void* residual;      /* [M, N] in the operand type, added to v (Identity residual, :873), or NULL */
     int ldr;
-    int act;                   /* 0 none, 1 SiLU on the result (:820) */
-    float* out_f32;            /* optional float32 output */
+    int act;                   /* 0 none, 1 SiLU on v before it is stored (:820); not combined with gn outputs */
+    float* out_f32;            /* optional float32 output of v */
     int ldo_f32;
-    void* out_bf16;            /* optional bfloat16 output */
-    int ldo_bf16;
+    void* out_op;              /* optional output of v in the operand type */
+    int ldo_op;
+    int n_gn;                  /* 0..2 fused SiLU(GroupNorm(v)) outputs */
+    adcdiff_gn_out gn[2];
+    float gn_eps;
 } adcdiff_gemm_args;
 int adcdiff_gemm(const adcdiff_gemm_args* args, adcdiff_stream_t stream);
 

@@ -42,19 +42,62 @@ def test_gemm_segments_and_epilogue(dtype, M, N, Ks):
     idx = rng.integers(0, 10, M).astype(np.int64)
     td = torch.bfloat16 if dtype == "bf16" else torch.float32
     if dtype == "bf16":
-        As_r, W_r = [_bf16_round(a) for a in As], _bf16_round(W)
+        As_r, W_r, res_r = [_bf16_round(a) for a in As], _bf16_round(W), _bf16_round(res)
     else:
-        As_r, W_r = As, W
-    ref = np.concatenate(As_r, 1).astype(np.float64) @ W_r.astype(np.float64).T + bias + table[idx] + res
+        As_r, W_r, res_r = As, W, res
+    prod = np.concatenate(As_r, 1).astype(np.float64) @ W_r.astype(np.float64).T
+    ref = prod + bias + table[idx] + res_r
     out = ops.gemm([_t(a, td) for a in As], _t(W, td), bias=_t(bias), rowbias=_t(table), rowbias_idx=_t(idx, torch.int64),
-                   residual=_t(res), dtype=dtype)
+                   residual=_t(res, td), dtype=dtype)
     assert rel_err(out.cpu().numpy(), ref) < (1e-5 if dtype == "bf16" else 2e-6)
-    # SiLU epilogue, broadcast row bias, bf16 output, partial store
-    ref2 = np.concatenate(As_r, 1).astype(np.float64) @ W_r.astype(np.float64).T + table[3]
+    # SiLU epilogue, broadcast row bias, operand-typed output only, partial store
+    ref2 = prod + table[3]
     ref2 = ref2 / (1 + np.exp(-ref2))
-    out2 = ops.gemm([_t(a, td) for a in As], _t(W, td), rowbias=_t(table[3]), act=1, out_bf16=True, m_valid=M - 5, dtype=dtype)
+    out2 = ops.gemm([_t(a, td) for a in As], _t(W, td), rowbias=_t(table[3]), act=1, out_f32=False, out_op=True, m_valid=M - 5,
+                    dtype=dtype)
+    assert out2.dtype == td
     got = out2.float().cpu().numpy()
-    assert rel_err(got[:M - 5], ref2[:M - 5]) < 8e-3
+    assert rel_err(got[:M - 5], ref2[:M - 5]) < (8e-3 if dtype == "bf16" else 2e-6)
+
+
+def _gn_silu_ref(v, gamma, beta, gs):
+    M, N = v.shape
+    vg = v.reshape(M, N // gs, gs)
+    y = (vg - vg.mean(2, keepdims=True)) / np.sqrt(vg.var(2, keepdims=True) + 1e-5)
+    y = y.reshape(M, N) * gamma + beta
+    return y / (1 + np.exp(-y))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("N,gs_pair", [(128, (4, 128)), (256, (8, 16)), (256, (32, 64)), (64, (4, 64)), (192, (16, 32)), (384, (128, 8))])
+def test_gemm_fused_groupnorm_outputs(dtype, N, gs_pair):
+    """The epilogue's SiLU(GroupNorm(v)) outputs for every supported group size, next to v itself."""
+    rng = np.random.default_rng(N + gs_pair[0])
+    M, K = 256, 192
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32) * 3
+    bias = rng.standard_normal(N).astype(np.float32)
+    gam = [(1 + 0.2 * rng.standard_normal(N)).astype(np.float32) for _ in range(2)]
+    bet = [(0.1 * rng.standard_normal(N)).astype(np.float32) for _ in range(2)]
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    A_r, W_r = (_bf16_round(A), _bf16_round(W)) if dtype == "bf16" else (A, W)
+    v = A_r.astype(np.float64) @ W_r.astype(np.float64).T + bias
+    if N % 128 != 0 and max(gs_pair) > 64:
+        with pytest.raises(adcdiff.AdcdiffError):
+            ops.gemm([_t(A, td)], _t(W, td), bias=_t(bias), gn=[(_t(gam[0]), _t(bet[0]), max(gs_pair))], dtype=dtype)
+        return
+    v32, vop, n0, n1 = ops.gemm([_t(A, td)], _t(W, td), bias=_t(bias), out_op=True, m_valid=M - 3,
+                                gn=[(_t(gam[0]), _t(bet[0]), gs_pair[0]), (_t(gam[1]), _t(bet[1]), gs_pair[1])], dtype=dtype)
+    tol = 1e-5 if dtype == "bf16" else 2e-6
+    assert rel_err(v32.cpu().numpy()[:M - 3], v[:M - 3]) < tol
+    for got, g, b, gs in ((n0, gam[0], bet[0], gs_pair[0]), (n1, gam[1], bet[1], gs_pair[1])):
+        ref = _gn_silu_ref(v, g, b, gs)
+        assert got.dtype == td
+        err = np.abs(got.float().cpu().numpy()[:M - 3] - ref[:M - 3]).max()
+        # groups of 4 / 8 channels amplify the accumulators' float32 rounding by 1 / (group std); see test_groupnorm_silu
+        assert err < (2.0 ** -8 * np.abs(ref).max() + 1e-5 if dtype == "bf16" else (3e-5 if gs <= 8 else 5e-6)), (gs, err)
+    if dtype == "bf16":
+        assert np.array_equal(vop.float().cpu().numpy()[:M - 3], _bf16_round(v32.cpu().numpy())[:M - 3])
 
 
 def test_gemm_asymmetric_layout():
