@@ -3,8 +3,9 @@
 The directory name is not a Python identifier; ``adcdiff.py`` at the repository root loads this
 package under the name ``adcdiff``.
 """
-from . import _lib, ops
+from . import _lib, ops, parallel
 from ._lib import AdcdiffError
+from .generation import MoleculeGenerator
 from .models import DiffusionModel, ResidualBlock, TimeEmbedding, UNetModel
 
-__all__ = ["DiffusionModel", "UNetModel", "TimeEmbedding", "ResidualBlock", "AdcdiffError", "ops", "_lib"]
+__all__ = ["DiffusionModel", "UNetModel", "TimeEmbedding", "ResidualBlock", "AdcdiffError", "MoleculeGenerator", "ops", "parallel", "_lib"]
