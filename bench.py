@@ -52,6 +52,22 @@ def build_model(dtype, weights):
     return model
 
 
+def measured_traffic(kernel_key):
+    """HBM bytes per launch of a kernel from the newest committed counter summary (profiles/*_traffic.json, produced by
+    profiles/collect.sh + summarize.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same benchmark)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            d = json.load(open(f))
+            v = d["kernels"].get(kernel_key, {}).get("hbm_bytes_per_launch")
+            if v:
+                best = (v, os.path.basename(f))
+        except Exception:
+            pass
+    return best
+
+
 def roofline(model, dtype, batch, window=8):
     """Live per-launch hipEvent timing of `window` denoising steps: achieved rate of the GEMM kernel
     (algorithmic FLOPs / its device time) and of the schedule-update kernel (algorithmic bytes / time)."""
@@ -68,8 +84,12 @@ def roofline(model, dtype, batch, window=8):
     main = {"bound": "mfma", "kernel": "gemm_nt_kernel<%s,128,128>" % ("bf16" if dtype == "bf16" else "float"),
             "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_TFLOPS[dtype], 4), "traffic": None,
+            "algorithmic_bytes_per_launch": sum(r["bytes"] for r in gemm) / max(1, len(gemm)),
             "launches": len(gemm), "avg_launch_ms": round(gemm_ms / max(1, len(gemm)), 4),
             "flop_per_launch": algo / max(1, len(gemm)), "gemm_ms_per_denoise_step": round(gemm_ms / window, 4)}
+    tr = measured_traffic("gemm_nt_kernel<bf16>" if dtype == "bf16" else "gemm_nt_kernel<float>") if batch == 65536 else None
+    if tr:
+        main["traffic"], main["traffic_source"] = tr[0], "profiles/" + tr[1]
     upd_ms = sum(r["ms"] for r in upd)
     upd_bytes = sum(r["bytes"] for r in upd)
     update = {"bound": "hbm", "kernel": "ddpm_step_kernel<false>", "achieved": round(upd_bytes / (upd_ms * 1e-3) / 1e9, 1),
