@@ -11,11 +11,10 @@
 // directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write); one LDS stage of 32 KiB per
 // workgroup, two barriers per K step, latency hidden by 3-4 resident workgroups per CU.  Workgroup ids
 // are remapped so that the N-tiles of one M-tile run on one XCD (they share the A rows in its L2).
-// Epilogue: the accumulators are transposed through LDS (64 rows x BN columns per pass) so that every
-// thread owns 32 contiguous columns of one row: bias / row-bias / residual loads and all stores are 16-byte
-// vectors over whole 128-byte lines, and GroupNorm statistics over groups of 4..128 channels are in-lane
-// sums plus at most two xor-shuffles (groups never cross the BN-wide tile).  The consumer's GroupNorm is
-// applied by the producer, so no layer output is ever re-read just to be normalised.
+// Epilogue (struct Epilogue below): each wave transposes its accumulators through a private LDS region so that
+// a lane owns 8 contiguous columns of a row; GroupNorm statistics are in-lane / DPP sums.  The consumer's
+// GroupNorm is applied by the producer, so no layer output is ever re-read just to be normalised.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -79,84 +78,207 @@ __device__ __forceinline__ void store8(T* dst, const float (&y)[8]) {
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void store32(T* dst, const float (&v)[32]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float y[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = v[8 * q + e];
-        store8<T>(dst + 8 * q, y);
-    }
+__device__ __forceinline__ void load8(const float* src, float (&y)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+    y[0] = a[0]; y[1] = a[1]; y[2] = a[2]; y[3] = a[3]; y[4] = b[0]; y[5] = b[1]; y[6] = b[2]; y[7] = b[3];
 }
 
-__device__ __forceinline__ void load32(const float* src, float (&y)[32]) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * q);
-        y[4 * q] = t[0]; y[4 * q + 1] = t[1]; y[4 * q + 2] = t[2]; y[4 * q + 3] = t[3];
-    }
+// Sum over LANES adjacent lanes (aligned group) with DPP row operations: quad_perm for xor 1 and 2, then
+// row_half_mirror (the quads are uniform by then, so mirroring within 8 lanes brings in the other quad).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int LANES>
+__device__ __forceinline__ float group_sum(float x) {
+    if constexpr (LANES >= 2) x += dpp_f<0xB1>(x);    // quad_perm [1,0,3,2]
+    if constexpr (LANES >= 4) x += dpp_f<0x4E>(x);    // quad_perm [2,3,0,1]
+    if constexpr (LANES >= 8) x += dpp_f<0x141>(x);   // row_half_mirror
+    return x;
 }
 
-__device__ __forceinline__ void add32(const float* src, float (&v)[32]) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * q);
-        v[4 * q] += t[0]; v[4 * q + 1] += t[1]; v[4 * q + 2] += t[2]; v[4 * q + 3] += t[3];
-    }
-}
+// ---- epilogue shared by the GEMM kernels -------------------------------------------------------------------
+// Every wave transposes its own WTM x WTN accumulator tile through a private LDS region, 32 rows at a time, so
+// that a lane owns 8 contiguous columns of one row (WTN / 8 lanes per row): no workgroup barrier, the two waves
+// of a SIMD interleave freely, every global store is a 16-byte piece of a full 128-byte line.  Column-dependent
+// inputs (bias + broadcast row bias, GroupNorm weight / bias of both outputs) are fetched into LDS at kernel start
+// and sit in registers for the whole tile.  GroupNorm groups of 4 / 8 channels are in-lane, 16..WTN channels are
+// DPP sums over 2..8 adjacent lanes; a group of 2 * WTN channels (128 at WTN = 64) spans the two waves wn, wn ^ 1,
+// which exchange (mean, centred sum of squares) through LDS once per step and combine them with the pairwise
+// (Chan) update -- the only place the epilogue uses a workgroup barrier.
+// C/D layouts: 16x16 -- col = l & 15, row = 4 * (l >> 4) + r; 32x32 -- col = l & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
+template <typename T, int NT, int BN, int WTM, int WTN, int TM, int TN>
+struct Epilogue {
+    static constexpr bool BF = sizeof(T) == 2;
+    static constexpr int TS = BF ? 16 : 32;
+    static constexpr int NACC = BF ? 4 : 16;
+    static constexpr int NWAVE = NT / 64;
+    static constexpr int CH = 32;                   // rows per chunk
+    static constexpr int NCHUNK = WTM / CH;
+    static constexpr int LPR = WTN / 8;             // lanes per row
+    static constexpr int RPS = 64 / LPR;            // rows per step
+    static constexpr int NSTEP = CH / RPS;
+    static constexpr int LDW = WTN + 4;             // floats per staged row
+    static constexpr int STAGE_BYTES = NWAVE * CH * LDW * 4;
+    static constexpr int PRM_BYTES = 5 * BN * 4;    // cb, gamma0, beta0, gamma1, beta1
+    static constexpr int XB = NWAVE * RPS * 2;      // floats of one exchange buffer: (mean, M2) per wave and row
+    static constexpr int XCH_BYTES = 4 * XB * 4;    // [step parity][GroupNorm output]
+    static constexpr int EXTRA_BYTES = PRM_BYTES + XCH_BYTES;
+    typedef float acc_t __attribute__((ext_vector_type(NACC)));
+    static_assert(NCHUNK >= 1 && NCHUNK <= 4 && CH % TS == 0 && (LPR == 8 || LPR == 4), "unsupported epilogue geometry");
 
-// SiLU(GroupNorm(v)) for the 32 columns of one row held by this lane; GS channels per group.  Groups of
-// 64 / 128 span 2 / 4 adjacent lanes (the threads of one row are adjacent lanes).  Statistics first (two
-// passes over the registers), then normalise / scale / activate / store in chunks of 8 columns so that only
-// 8 gamma and 8 beta values are live at a time.
-template <typename T, int GS>
-__device__ __forceinline__ void gn_silu_store(const float (&v)[32], const GnOut& g, long row, int col, float eps, bool live) {
-    constexpr int NG = GS <= 32 ? 32 / GS : 1;      // groups held by this lane
-    constexpr int GL = GS <= 32 ? GS : 32;          // columns of one group held by this lane
-    float mean[NG], rstd[NG];
-#pragma unroll
-    for (int n = 0; n < NG; ++n) {
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < GL; ++k) s += v[n * GL + k];
-        if constexpr (GS >= 64) s += __shfl_xor(s, 1);
-        if constexpr (GS == 128) s += __shfl_xor(s, 2);
-        mean[n] = s * (1.0f / GS);
-        float q = 0.0f;
-#pragma unroll
-        for (int k = 0; k < GL; ++k) { const float d = v[n * GL + k] - mean[n]; q += d * d; }
-        if constexpr (GS >= 64) q += __shfl_xor(q, 1);
-        if constexpr (GS == 128) q += __shfl_xor(q, 2);
-        rstd[n] = 1.0f / __builtin_sqrtf(q * (1.0f / GS) + eps);
-    }
-    T* const dst = reinterpret_cast<T*>(g.out) + row * g.ldo + col;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(g.gamma + col + 8 * c), g1 = *reinterpret_cast<const f32x4*>(g.gamma + col + 8 * c + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.beta + col + 8 * c), b1 = *reinterpret_cast<const f32x4*>(g.beta + col + 8 * c + 4);
-        float y[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 8 * c + e, n = k / GL;
-            const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
-            y[e] = silu_out<T>((v[k] - mean[n]) * rstd[n] * ga + be);
+    // Called by all threads at kernel start: column-dependent vectors of this block's BN columns -> LDS.
+    static __device__ __forceinline__ void stage_params(const GemmParams& p, int n0, int tid, float* prm) {
+        for (int idx = tid; idx < 5 * BN / 4; idx += NT) {
+            const int vec = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
+            f32x4 val = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (vec == 0) {
+                if (p.bias) val = *reinterpret_cast<const f32x4*>(p.bias + n0 + c);
+                if (p.rowbias && !p.rowbias_idx && p.ldrb == 0) {
+                    const f32x4 rb = *reinterpret_cast<const f32x4*>(p.rowbias + n0 + c);
+                    val[0] += rb[0]; val[1] += rb[1]; val[2] += rb[2]; val[3] += rb[3];
+                }
+            } else {
+                const int g = (vec - 1) >> 1;
+                if (g < p.n_gn) val = *reinterpret_cast<const f32x4*>(((vec - 1) & 1 ? p.gn[g].beta : p.gn[g].gamma) + n0 + c);
+            }
+            *reinterpret_cast<f32x4*>(prm + vec * BN + c) = val;
         }
-        if (live) store8<T>(dst + 8 * c, y);
     }
-}
 
-template <typename T>
-__device__ __forceinline__ void gn_dispatch(const float (&v)[32], const GnOut& g, long row, int col, float eps, bool live) {
-    switch (g.gs) {   // wave-uniform
-        case 4: gn_silu_store<T, 4>(v, g, row, col, eps, live); break;
-        case 8: gn_silu_store<T, 8>(v, g, row, col, eps, live); break;
-        case 16: gn_silu_store<T, 16>(v, g, row, col, eps, live); break;
-        case 32: gn_silu_store<T, 32>(v, g, row, col, eps, live); break;
-        case 64: gn_silu_store<T, 64>(v, g, row, col, eps, live); break;
-        default: gn_silu_store<T, 128>(v, g, row, col, eps, live); break;
+    template <int GS>
+    static __device__ __forceinline__ void gn_store(const float (&v)[8], const float (&gam)[8], const float (&bet)[8], T* dst, float eps,
+                                                    bool live, float* xch, int wave, int rr, int cg) {
+        float y[8];
+        if constexpr (GS == 4) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float mean = ((v[4 * h] + v[4 * h + 1]) + (v[4 * h + 2] + v[4 * h + 3])) * 0.25f;
+                float q = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float d = v[4 * h + k] - mean; q += d * d; }
+                const float rstd = 1.0f / __builtin_sqrtf(q * 0.25f + eps);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[4 * h + k] = silu_out<T>((v[4 * h + k] - mean) * rstd * gam[4 * h + k] + bet[4 * h + k]);
+            }
+        } else {
+            constexpr int IN_WAVE = GS <= WTN ? GS : WTN;   // channels of the group inside this wave
+            constexpr int LANES = IN_WAVE / 8;
+            float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            s = group_sum<LANES>(s);
+            float mean = s * (1.0f / IN_WAVE);
+            float q = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float d = v[k] - mean; q += d * d; }
+            q = group_sum<LANES>(q);
+            if constexpr (GS > WTN) {
+                // the other half of the group lives in wave ^ 1: exchange (mean, M2) and merge
+                if (cg == 0) { xch[(wave * RPS + rr) * 2] = mean; xch[(wave * RPS + rr) * 2 + 1] = q; }
+                __syncthreads();
+                const float om = xch[((wave ^ 1) * RPS + rr) * 2], oq = xch[((wave ^ 1) * RPS + rr) * 2 + 1];
+                const float delta = om - mean;
+                q = q + oq + delta * delta * (0.5f * IN_WAVE);
+                mean = 0.5f * (mean + om);
+            }
+            const float rstd = 1.0f / __builtin_sqrtf(q * (1.0f / GS) + eps);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = silu_out<T>((v[k] - mean) * rstd * gam[k] + bet[k]);
+        }
+        if (live) store8<T>(dst, y);
     }
-}
+
+    static __device__ __forceinline__ void gn_dispatch(int gs, const float (&v)[8], const float (&gam)[8], const float (&bet)[8], T* dst,
+                                                       float eps, bool live, float* xch, int wave, int rr, int cg) {
+        switch (gs) {   // workgroup-uniform
+            case 4: gn_store<4>(v, gam, bet, dst, eps, live, xch, wave, rr, cg); break;
+            case 8: gn_store<8>(v, gam, bet, dst, eps, live, xch, wave, rr, cg); break;
+            case 16: gn_store<16>(v, gam, bet, dst, eps, live, xch, wave, rr, cg); break;
+            case 32: gn_store<32>(v, gam, bet, dst, eps, live, xch, wave, rr, cg); break;
+            case 64: gn_store<64>(v, gam, bet, dst, eps, live, xch, wave, rr, cg); break;
+            default:
+                if constexpr (WTN == 64) gn_store<128>(v, gam, bet, dst, eps, live, xch, wave, rr, cg);
+                break;
+        }
+    }
+
+    // smem_epi: NWAVE private staging regions (reusing the main loop's LDS); prm / xch: behind the main loop's LDS.
+    static __device__ __forceinline__ void run(const acc_t (&acc)[TM][TN], const GemmParams& p, int m0, int n0, int wm, int wn, int wave,
+                                               int lane, float* smem_epi, float* prm, float* xch_base) {
+        float* const stage = smem_epi + wave * (CH * LDW);
+        const int ccol = BF ? (lane & 15) : (lane & 31);
+        const int crow0 = BF ? 4 * (lane >> 4) : 4 * (lane >> 5);
+        const int cg = lane % LPR, rr = lane / LPR;
+        const int bcol = wn * WTN + cg * 8;      // column inside the block tile
+        const long col = n0 + bcol;
+        float cb[8], g0[8], b0[8], g1[8], b1[8];
+        load8(prm + bcol, cb);
+        load8(prm + BN + bcol, g0);
+        load8(prm + 2 * BN + bcol, b0);
+        load8(prm + 3 * BN + bcol, g1);
+        load8(prm + 4 * BN + bcol, b1);
+        const T* const resp = reinterpret_cast<const T*>(p.residual);
+        const bool row_rb = p.rowbias != nullptr && (p.rowbias_idx != nullptr || p.ldrb != 0);
+        int step_id = 0;
+#pragma unroll
+        for (int h = 0; h < NCHUNK; ++h) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (i / (CH / TS) != h) continue;   // compile-time after unrolling
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < NACC; ++r) {
+                        const int crow = i * TS + crow0 + (BF ? r : (r & 3) + 8 * (r >> 2)) - h * CH;
+                        stage[crow * LDW + j * TS + ccol] = acc[i][j][r];
+                    }
+            }
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st, ++step_id) {
+                const int crow = st * RPS + rr;
+                const long row = m0 + wm * WTM + h * CH + crow;
+                const bool live = row < p.m_valid;
+                const long lrow = live ? row : 0;    // dead rows read row 0's side inputs (always valid) and store nothing
+                float v[8];
+                load8(stage + crow * LDW + cg * 8, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += cb[k];
+                if (row_rb) {
+                    const long ridx = p.rowbias_idx ? (long)p.rowbias_idx[lrow] : lrow;
+                    float t[8];
+                    load8(p.rowbias + ridx * p.ldrb + col, t);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += t[k];
+                }
+                if (resp) {
+                    const T* rp = resp + lrow * p.ldr + col;
+                    if constexpr (BF) {
+                        const bf16x8 t = *reinterpret_cast<const bf16x8*>(rp);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+                    } else {
+                        float t[8];
+                        load8(reinterpret_cast<const float*>(rp), t);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] += t[k];
+                    }
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = silu_f(v[k]);
+                }
+                if (p.out_f32 && live) store8<float>(p.out_f32 + row * p.ldo_f32 + col, v);
+                if (p.out_op && live) store8<T>(reinterpret_cast<T*>(p.out_op) + row * p.ldo_op + col, v);
+                float* const xch = xch_base + (step_id & 1) * (2 * XB);
+                if (p.n_gn > 0)
+                    gn_dispatch(p.gn[0].gs, v, g0, b0, reinterpret_cast<T*>(p.gn[0].out) + row * p.gn[0].ldo + col, p.eps, live, xch, wave, rr, cg);
+                if (p.n_gn > 1)
+                    gn_dispatch(p.gn[1].gs, v, g1, b1, reinterpret_cast<T*>(p.gn[1].out) + row * p.gn[1].ldo + col, p.eps, live, xch + XB,
+                                wave, rr, cg);
+            }
+        }
+    }
+};
 
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
@@ -167,9 +289,13 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
     constexpr int TM = WTM / TS, TN = WTN / TS;
     constexpr int NACC = BF ? 4 : 16;
     constexpr int A_PIECES = BM / 8 / 4, B_PIECES = BN / 8 / 4;   // 1 KiB pieces (8 rows) per wave
+    typedef Epilogue<T, 256, BN, WTM, WTN, TM, TN> Epi;
+    constexpr int MAIN_BYTES = (BM + BN) * 128 > Epi::STAGE_BYTES ? (BM + BN) * 128 : Epi::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sa = smem;
     char* const sb = smem + A_BYTES;
+    float* const prm = reinterpret_cast<float*>(smem + MAIN_BYTES);
+    float* const xch = prm + 5 * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -179,6 +305,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
     const int nwg = gridDim.x;
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
+    Epi::stage_params(p, n0, tid, prm);
 
     // staging: lane l of piece q fills LDS row 8q + (l >> 3), chunk position l & 7, which holds the logical
     // chunk (l & 7) ^ ((row >> 1) & 7): the swizzle is applied on the SOURCE address, the LDS image stays
@@ -282,77 +409,154 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: transpose through LDS, then one thread = 32 contiguous columns of one row ----
-    // C/D layouts: 16x16 -- col = l & 15, row = 4 * (l >> 4) + r; 32x32 -- col = l & 31,
-    // row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
-    constexpr int TPR = BN / 32;        // threads per row
-    constexpr int RPP = 256 / TPR;      // block rows per pass
-    constexpr int PRW = RPP / 2;        // rows of each wave tile per pass
-    constexpr int NPASS = WTM / PRW;
-    constexpr int LDSW = BN + 4;        // padded row of the staging image, in floats
-    float* const stage = reinterpret_cast<float*>(smem);
-    const int ccol = BF ? (lane & 15) : (lane & 31);
-    const int crow0 = BF ? 4 * (lane >> 4) : 4 * (lane >> 5);
-    const int erow = tid / TPR, echunk = tid % TPR;
-    const int col = n0 + echunk * 32;
-    const T* const resp = reinterpret_cast<const T*>(p.residual);
-    auto pass = [&](auto hc) __attribute__((always_inline)) {
-        constexpr int h = decltype(hc)::value;
-        if (h > 0) __syncthreads();
+    Epi::run(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
+}
+
+// ---- 256 x 256 tile, 8 waves (2 x 4, 128 x 64 per wave), bf16 ------------------------------------------------
+// For the large layers (M, N multiples of 256).  Two 64 KiB LDS stages; the LDS-DMA of K tile t+2 is issued right
+// after the barrier that ends tile t and has the whole of tile t+1's 64 MFMAs per wave to land, so the only wait in
+// the loop finds its data already there.  One barrier per K tile, one workgroup (2 waves per SIMD) per CU.
+// LDS-DMA issued from inline asm: hipcc does not track it, so it inserts no vmcnt(0) in front of the next ds_read
+// (which it does for the builtin whenever the destination may alias) and the prefetch really stays in flight
+// under the MFMAs; the loop counts vmcnt by hand.  M0 carries the wave-uniform LDS byte address and is restored.
+__device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmParams p) {
+    typedef bf16_t T;
+    constexpr int BM = 256, BN = 256, WTM = 128, WTN = 64, TM = 8, TN = 4, STAGE_BYTES = 65536;
+    typedef Epilogue<T, 512, BN, WTM, WTN, TM, TN> Epi;
+    static_assert(Epi::STAGE_BYTES <= 2 * STAGE_BYTES, "epilogue staging must fit the main-loop LDS");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const prm = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);
+    float* const xch = prm + 5 * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
+    Epi::stage_params(p, n0, tid, prm);
+
+    // per-lane source addresses of this wave's four A pieces and four W pieces (8 rows x 128 B each) at k = 0 of the
+    // current segment; the swizzle (chunk ^ ((row >> 1) & 7)) sits in the source address, the LDS image is linear
+    const int prow = lane >> 3;
+    int a_row[4];
+    long sw[4];
+    const char* a_src[4];
+    const char* w_src[4];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if (i / (PRW / TS) != h) continue;   // folds at compile time: h and i are constants after unrolling
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * (wave * 4 + j) + prow;
+        sw[j] = (long)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+        a_row[j] = m0 + row;
+        a_src[j] = reinterpret_cast<const char*>(p.A[0]) + (long)a_row[j] * p.lda[0] * 2 + sw[j];
+        w_src[j] = reinterpret_cast<const char*>(p.W) + (long)(n0 + row) * p.ldw * 2 + sw[j];
+    }
+
+    f32x4 acc[TM][TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < NACC; ++r) {
-                    const int wrow = i * TS + crow0 + (BF ? r : (r & 3) + 8 * (r >> 2)) - h * PRW;
-                    stage[(wm * PRW + wrow) * LDSW + wn * WTN + j * TS + ccol] = acc[i][j][r];
-                }
-        }
-        __syncthreads();
-        const long row = m0 + (erow / PRW) * WTM + h * PRW + (erow % PRW);
-        const bool live = row < p.m_valid;
-        const long lrow = live ? row : m0;   // dead rows compute on row m0's side inputs and store nothing
-        float v[32];
-        load32(stage + erow * LDSW + echunk * 32, v);
-        if (p.bias) add32(p.bias + col, v);
-        if (p.rowbias) {
-            const long ridx = p.rowbias_idx ? (long)p.rowbias_idx[lrow] : lrow;
-            add32(p.rowbias + ridx * p.ldrb + col, v);
-        }
-        if (resp) {
-            const T* rp = resp + lrow * p.ldr + col;
-            if constexpr (BF) {
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int nt = p.nt_total;
+
+    int iseg = 0, itt = 0;   // issue cursor over the K segments
+#define ADCDIFF_ISSUE_NEXT(STAGE)                                                                          \
+    do {                                                                                                   \
+        if (itt == p.ktiles[iseg]) {                                                                       \
+            ++iseg; itt = 0;                                                                               \
+            if (itt == p.ktiles[iseg]) ++iseg;                                                             \
+            const char* nb = reinterpret_cast<const char*>(iseg == 1 ? p.A[1] : p.A[2]);                   \
+            const long nl = (long)(iseg == 1 ? p.lda[1] : p.lda[2]) * 2;                                   \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) a_src[j] = nb + (long)a_row[j] * nl + sw[j];     \
+        }                                                                                                  \
+        const unsigned sbase = lds0 + (STAGE) * STAGE_BYTES + wave * 4096;                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+            glds16_untracked(a_src[j], sbase + j * 1024);                                                  \
+            a_src[j] += 128;                                                                               \
+        }                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+            glds16_untracked(w_src[j], sbase + 32768 + j * 1024);                                          \
+            w_src[j] += 128;                                                                               \
+        }                                                                                                  \
+        ++itt;                                                                                             \
+    } while (0)
+
+    ADCDIFF_ISSUE_NEXT(0);
+    if (nt > 1) {
+        ADCDIFF_ISSUE_NEXT(1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nt; ++t) {
+        const char* sa = smem + (t & 1) * STAGE_BYTES;
+        const char* sb = sa + 32768;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bf16x8 t = *reinterpret_cast<const bf16x8*>(rp + 8 * q);
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = 4 * ks + fchunk;
+            uint4 af[TM], bfr[TN];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[8 * q + e] += (float)t[e];
-                }
-            } else {
-                add32(reinterpret_cast<const float*>(rp), v);
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * WTN + j * 16 + frow;
+                bfr[j] = *reinterpret_cast<const uint4*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
             }
-        }
-        if (p.act == 1) {
 #pragma unroll
-            for (int k = 0; k < 32; ++k) v[k] = silu_f(v[k]);
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * WTM + i * 16 + frow;
+                af[i] = *reinterpret_cast<const uint4*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                        __builtin_bit_cast(bf16x8, bfr[j]), acc[i][j], 0, 0, 0);
         }
-        if (p.out_f32 && live) store32<float>(p.out_f32 + row * p.ldo_f32 + col, v);
-        if (p.out_op && live) store32<T>(reinterpret_cast<T*>(p.out_op) + row * p.ldo_op + col, v);
-        if (p.n_gn > 0) gn_dispatch<T>(v, p.gn[0], row, col, p.eps, live);
-        if (p.n_gn > 1) gn_dispatch<T>(v, p.gn[1], row, col, p.eps, live);
-    };
-    pass(std::integral_constant<int, 0>{});
-    if constexpr (NPASS > 1) pass(std::integral_constant<int, 1>{});
-    static_assert(NPASS <= 2, "at most two epilogue passes");
+        // tile t+1 was issued a whole tile of MFMAs ago: this wait normally finds it landed.  The barrier then says
+        // both "every wave's part of tile t+1 is in LDS" and "every wave has finished reading stage t & 1".
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) ADCDIFF_ISSUE_NEXT(t & 1);
+    }
+#undef ADCDIFF_ISSUE_NEXT
+    __syncthreads();
+    Epi::run(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
+}
+
+static int launch256(const GemmParams& p, hipStream_t stream) {
+    constexpr int smem = 2 * 65536 + Epilogue<bf16_t, 512, 256, 128, 64, 8, 4>::EXTRA_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    GemmParams q = p;
+    q.ntn = p.N / 256;
+    const int grid = (p.M / 256) * q.ntn;
+    hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(grid), dim3(512), smem, stream, q);
+    return check_launch("gemm256");
 }
 
 template <typename T, int BM, int BN>
 static int launch(const GemmParams& p, hipStream_t stream) {
+    constexpr int TS = sizeof(T) == 2 ? 16 : 32;
+    typedef Epilogue<T, 256, BN, BM / 2, BN / 2, BM / 2 / TS, BN / 2 / TS> Epi;
     constexpr int main_bytes = (BM + BN) * 128;
-    constexpr int epi_bytes = (256 / (BN / 32)) * (BN + 4) * 4;
-    constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+    constexpr int smem = (main_bytes > Epi::STAGE_BYTES ? main_bytes : Epi::STAGE_BYTES) + Epi::EXTRA_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN>),
@@ -424,7 +628,26 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     const double nout = (a.out_f32 ? 4.0 : 0.0) + esz * ((a.out_op ? 1 : 0) + a.n_gn);
     TimingScope ts(a.dtype == ADCDIFF_BF16 ? ADCDIFF_KIND_GEMM_BF16 : ADCDIFF_KIND_GEMM_F32, a.M, a.N, ktot, 2.0 * a.M * a.N * ktot,
                    esz * ((double)a.M * ktot + (double)a.N * ktot) + (double)a.M * a.N * (nout + (a.residual ? esz : 0.0)), stream);
-    if (a.dtype == ADCDIFF_BF16) return wide ? launch<bf16_t, 128, 128>(p, stream) : launch<bf16_t, 128, 64>(p, stream);
+    // Kernel choice for bf16, from A/B timings of both kernels on the denoiser's layer shapes at M = 65536: the
+    // 256 x 256 kernel (one workgroup per CU, prefetch under the MFMAs) wins once the K loop is long enough to
+    // amortise its exposed prologue / epilogue; the 128-row kernel (3-4 workgroups per CU) wins elsewhere.
+    if (a.dtype == ADCDIFF_BF16 && a.M % 256 == 0 && a.N % 256 == 0 && a.tile_hint != 128) {
+        static const int forced = [] { const char* e = getenv("ADCDIFF_GEMM_TILE"); return e ? atoi(e) : 0; }();   // measurement aid
+        if (forced == 256) return launch256(p, stream);
+        const bool enough_tiles = forced != 128 && (long)(a.M / 256) * (a.N / 256) >= 192;
+        const bool long_k = ktot >= 2048;
+        if (a.tile_hint == 256 || (enough_tiles && long_k)) return launch256(p, stream);
+    }
+    // few rows (the float32 batch-4096 case, small generation batches): 64 x 64 tiles give four times the workgroups
+    bool small = (long)(a.M / 128) * (a.N / (wide ? 128 : 64)) < 256 && a.tile_hint != 128;
+    // only where the GroupNorm groups stay inside a 32-column wave tile: every kernel then sums a group in the same
+    // order, so a row's result does not depend on the batch size it is computed in (bit for bit)
+    for (int g = 0; g < a.n_gn; ++g) small = small && a.gn[g].group_size <= 32;
+    if (a.dtype == ADCDIFF_BF16) {
+        if (small) return launch<bf16_t, 64, 64>(p, stream);
+        return wide ? launch<bf16_t, 128, 128>(p, stream) : launch<bf16_t, 128, 64>(p, stream);
+    }
+    if (small) return launch<float, 64, 64>(p, stream);
     return wide ? launch<float, 128, 128>(p, stream) : launch<float, 128, 64>(p, stream);
 }
 

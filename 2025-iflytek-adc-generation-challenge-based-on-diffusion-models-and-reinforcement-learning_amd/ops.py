@@ -47,7 +47,7 @@ def _operand(x, code):
 
 
 def gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, act=0, out_f32=True, out_op=False, gn=(),
-         m_valid=None, dtype="fp32", eps=1e-5):
+         m_valid=None, dtype="fp32", eps=1e-5, tile_hint=0):
     """adcdiff_gemm: v = [A0|A1|A2] @ w.T + bias + rowbias + residual.
 
     a_list: operand tensors [M, K_s] (M a multiple of 128) already in the operand dtype; w [N, sum K_s]; residual in the
@@ -73,6 +73,7 @@ def gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, ac
     if residual is not None:
         args.residual, args.ldr = residual.data_ptr(), residual.stride(0)
     args.act = act
+    args.tile_hint = tile_hint
     outs = []
     if out_f32:
         o = torch.empty((M, N), device=w.device, dtype=torch.float32)

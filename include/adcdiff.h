@@ -89,6 +89,7 @@ typedef struct adcdiff_gemm_args {
     int n_gn;                  /* 0..2 fused SiLU(GroupNorm(v)) outputs */
     adcdiff_gn_out gn[2];
     float gn_eps;
+    int tile_hint;             /* 0 = choose; 128 / 256 = force that tile kernel where the shape allows (A/B measurements, tests) */
 } adcdiff_gemm_args;
 int adcdiff_gemm(const adcdiff_gemm_args* args, adcdiff_stream_t stream);
 

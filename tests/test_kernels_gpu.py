@@ -100,6 +100,36 @@ def test_gemm_fused_groupnorm_outputs(dtype, N, gs_pair):
         assert np.array_equal(vop.float().cpu().numpy()[:M - 3], _bf16_round(v32.cpu().numpy())[:M - 3])
 
 
+@pytest.mark.parametrize("Ks", [[64], [128, 64, 192], [512, 1024]])
+def test_gemm_256_tile_kernel_matches_128_tile_kernel(Ks):
+    """The 256 x 256 eight-wave kernel (used for the large layers) against float64 and against the 128-row kernel,
+    with every epilogue output; K = 64 is the single-tile case, the others exercise the prefetch ring and segments."""
+    rng = np.random.default_rng(sum(Ks))
+    M, N = 768, 512
+    As = [rng.standard_normal((M, k)).astype(np.float32) for k in Ks]
+    W = (rng.standard_normal((N, sum(Ks))) / np.sqrt(sum(Ks))).astype(np.float32) * 2
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    table = rng.standard_normal((7, N)).astype(np.float32)
+    idx = rng.integers(0, 7, M).astype(np.int64)
+    gam = (1 + 0.2 * rng.standard_normal(N)).astype(np.float32)
+    bet = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    bf = torch.bfloat16
+    kw = dict(bias=_t(bias), rowbias=_t(table), rowbias_idx=_t(idx, torch.int64), residual=_t(res, bf), out_op=True,
+              gn=[(_t(gam), _t(bet), 16), (_t(gam), _t(bet), 128)], m_valid=M - 9, dtype="bf16")
+    big = ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=256, **kw)
+    small = ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=128, **kw)
+    v = np.concatenate([_bf16_round(a) for a in As], 1).astype(np.float64) @ _bf16_round(W).astype(np.float64).T + bias + table[idx] + \
+        _bf16_round(res)
+    assert rel_err(big[0].cpu().numpy()[:M - 9], v[:M - 9]) < 1e-5
+    for b, s_ in zip(big, small):
+        # same products and the same k order within a tile, but the two kernels split K across MFMA chains alike, so
+        # the float32 sums agree to rounding; the bf16 outputs may differ in the last bit
+        assert rel_err(b.float().cpu().numpy()[:M - 9], s_.float().cpu().numpy()[:M - 9]) < 8e-3
+    ref = _gn_silu_ref(v, gam, bet, 128)
+    assert np.abs(big[3].float().cpu().numpy()[:M - 9] - ref[:M - 9]).max() < 2.0 ** -8 * np.abs(ref).max() + 1e-5
+
+
 def test_gemm_asymmetric_layout():
     """A = I against an asymmetric W catches a transposed or permuted accumulator map."""
     M = N = K = 128
@@ -107,6 +137,10 @@ def test_gemm_asymmetric_layout():
     for dtype, td in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
         out = ops.gemm([_t(np.eye(M, K, dtype=np.float32), td)], _t(W, td), dtype=dtype).cpu().numpy()
         assert np.array_equal(out, _bf16_round(W).T if dtype == "bf16" else W.T)
+    M = N = K = 256
+    W = (np.arange(N)[:, None] * 3 + np.arange(K)[None, :] * 0.5).astype(np.float32)
+    out = ops.gemm([_t(np.eye(M, K, dtype=np.float32), torch.bfloat16)], _t(W, torch.bfloat16), dtype="bf16", tile_hint=256).cpu().numpy()
+    assert np.array_equal(out, _bf16_round(W).T)
 
 
 @pytest.mark.parametrize("C,G", [(128, 32), (256, 32), (512, 32), (1024, 32), (2048, 32), (4096, 32), (192, 32), (64, 32), (2048, 16)])
