@@ -50,6 +50,16 @@ class UnetParams(C.Structure):
                 ("sinusoid_freq", c_fp)]
 
 
+class BlockGrads(C.Structure):
+    _fields_ = [(f, c_fp) for f in BLOCK_FIELDS]
+
+
+class UnetGrads(C.Structure):
+    _fields_ = [("time_lin1_w", c_fp), ("time_lin1_b", c_fp), ("time_lin2_w", c_fp), ("time_lin2_b", c_fp),
+                ("blocks", BlockGrads * 10),
+                ("out_norm_w", c_fp), ("out_norm_b", c_fp), ("out_w", c_fp), ("out_b", c_fp)]
+
+
 class TimingRecord(C.Structure):
     _fields_ = [("kind", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ms", C.c_float), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -84,6 +94,10 @@ SIGNATURES = {
     "adcdiff_ddim_sample_loop": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.POINTER(C.c_int),
                                            C.POINTER(DdimCoef), C.c_int, c_fp, C.c_longlong, C.c_uint64, C.c_uint64, c_fp,
                                            C.c_size_t, c_fp]),
+    "adcdiff_unet_train_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "adcdiff_unet_train_forward": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp, C.c_float, C.c_uint64, c_fp, C.c_int, c_fp, C.c_size_t, c_fp]),
+    "adcdiff_mse_loss_grad": (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_float, c_fp, c_fp]),
+    "adcdiff_unet_backward": (C.c_int, [c_fp, c_fp, C.c_int, C.POINTER(UnetGrads), c_fp, C.c_size_t, c_fp]),
     "adcdiff_timing_begin": (C.c_int, [C.c_int]),
     "adcdiff_timing_end": (C.c_int, [C.POINTER(TimingRecord), C.c_int, C.POINTER(C.c_int)]),
 }

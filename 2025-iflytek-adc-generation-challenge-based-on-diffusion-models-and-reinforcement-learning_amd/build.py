@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadcdiff.so")
-SOURCES = [("gemm.hip", []), ("elementwise.hip", ["-ffp-contract=off"]), ("unet.hip", [])]
+SOURCES = [("gemm.hip", []), ("elementwise.hip", ["-ffp-contract=off"]), ("unet.hip", []), ("train.hip", [])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -23,7 +23,7 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "adcdiff.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "unet_plan.h"), os.path.join(os.path.dirname(HERE), "include", "adcdiff.h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []

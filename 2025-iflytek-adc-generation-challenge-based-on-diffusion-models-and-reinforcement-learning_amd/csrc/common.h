@@ -74,4 +74,15 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint32_t stream, 
     return z;
 }
 
+// Dropout keep factors (0 or 1 / (1 - p)) for columns 4q..4q+3 of a row: Philox stream 5, step field = layer index.
+__device__ __forceinline__ f32x4 dropout_keep4(uint64_t seed, uint32_t layer, uint64_t row, uint32_t quad, float p) {
+    uint32_t c0 = quad, c1 = (uint32_t)row, c2 = layer, c3 = 5u;
+    philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float scale = 1.0f / (1.0f - p);
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    f32x4 k;
+    k[0] = c0 >= thr ? scale : 0.0f; k[1] = c1 >= thr ? scale : 0.0f; k[2] = c2 >= thr ? scale : 0.0f; k[3] = c3 >= thr ? scale : 0.0f;
+    return k;
+}
+
 }  // namespace adcdiff

@@ -48,7 +48,8 @@ template <typename OutT>
 __global__ __launch_bounds__(256) void gn_silu_vec_kernel(const float* __restrict__ x, int ldx, long total4, int c4,
                                                           int lanes_per_group, float inv_gs, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, OutT* __restrict__ out,
-                                                          int ldo, OutT* __restrict__ raw, int ldraw) {
+                                                          int ldo, OutT* __restrict__ raw, int ldraw, float drop_p, uint64_t drop_seed,
+                                                          uint32_t drop_layer) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     const bool live = e < total4;
     const long ee = live ? e : 0;
@@ -68,6 +69,11 @@ __global__ __launch_bounds__(256) void gn_silu_vec_kernel(const float* __restric
     f32x4 y;
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[i] = silu_f(d[i] * rstd * g[i] + b[i]);
+    if (drop_p > 0.0f) {   // training-mode dropout (diffusion_model.py:898): keep with probability 1 - p, scale by 1 / (1 - p)
+        const f32x4 keep = dropout_keep4(drop_seed, drop_layer, (uint64_t)row, (uint32_t)(col >> 2), drop_p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] *= keep[i];
+    }
     if constexpr (sizeof(OutT) == 4) {
         *reinterpret_cast<f32x4*>(out + row * ldo + col) = y;
         if (raw) *reinterpret_cast<f32x4*>(raw + row * ldraw + col) = v;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void gn_silu_generic_kernel(const float* __res
 
 template <typename OutT>
 static int gn_launch(const float* x, int ldx, int M, int C, int groups, const float* gamma, const float* beta, float eps,
-                     OutT* out, int ldo, OutT* raw, int ldraw, hipStream_t stream) {
+                     OutT* out, int ldo, OutT* raw, int ldraw, hipStream_t stream, float drop_p, uint64_t drop_seed, uint32_t drop_layer) {
     const int gs = C / groups;
     const bool pow2 = (gs & (gs - 1)) == 0;
     const bool vec = pow2 && gs >= 4 && gs <= 256 && (ldx % 4 == 0) && (ldo % 4 == 0) && (!raw || ldraw % 4 == 0) &&
@@ -117,8 +123,9 @@ static int gn_launch(const float* x, int ldx, int M, int C, int groups, const fl
         const long total4 = (long)M * (C / 4);
         const long blocks = (total4 + 255) / 256;
         hipLaunchKernelGGL((gn_silu_vec_kernel<OutT>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, total4, C / 4, gs / 4,
-                           1.0f / (float)gs, gamma, beta, eps, out, ldo, raw, ldraw);
+                           1.0f / (float)gs, gamma, beta, eps, out, ldo, raw, ldraw, drop_p, drop_seed, drop_layer);
     } else {
+        if (drop_p > 0.0f) return fail(ADCDIFF_E_BADARG, "groupnorm_silu: dropout needs group sizes that are powers of two >= 4");
         const long total = (long)M * groups;
         const long blocks = (total + 255) / 256;
         hipLaunchKernelGGL((gn_silu_generic_kernel<OutT>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, total, groups, gs,
@@ -128,7 +135,8 @@ static int gn_launch(const float* x, int ldx, int M, int C, int groups, const fl
 }
 
 int groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const float* gamma, const float* beta, float eps,
-                   int out_dtype, void* out, int ldo, void* raw_out, int ldraw, hipStream_t stream) {
+                   int out_dtype, void* out, int ldo, void* raw_out, int ldraw, hipStream_t stream, float drop_p, uint64_t drop_seed,
+                   uint32_t drop_layer) {
     if (!x || !gamma || !beta || !out || M <= 0 || C <= 0 || groups <= 0 || C % groups != 0 || ldx < C || ldo < C)
         return fail(ADCDIFF_E_BADARG, "groupnorm_silu: bad arguments (M=%d C=%d groups=%d ldx=%d ldo=%d)", M, C, groups, ldx, ldo);
     const double osz = out_dtype == ADCDIFF_BF16 ? 2.0 : 4.0;
@@ -136,10 +144,10 @@ int groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const floa
     if (raw_out && ldraw < C) return fail(ADCDIFF_E_BADARG, "groupnorm_silu: ldraw=%d < C=%d", ldraw, C);
     if (out_dtype == ADCDIFF_F32)
         return gn_launch<float>(x, ldx, M, C, groups, gamma, beta, eps, reinterpret_cast<float*>(out), ldo,
-                                reinterpret_cast<float*>(raw_out), ldraw, stream);
+                                reinterpret_cast<float*>(raw_out), ldraw, stream, drop_p, drop_seed, drop_layer);
     if (out_dtype == ADCDIFF_BF16)
         return gn_launch<bf16_t>(x, ldx, M, C, groups, gamma, beta, eps, reinterpret_cast<bf16_t*>(out), ldo,
-                                 reinterpret_cast<bf16_t*>(raw_out), ldraw, stream);
+                                 reinterpret_cast<bf16_t*>(raw_out), ldraw, stream, drop_p, drop_seed, drop_layer);
     return fail(ADCDIFF_E_BADARG, "groupnorm_silu: unknown dtype %d", out_dtype);
 }
 
@@ -326,7 +334,7 @@ extern "C" const char* adcdiff_last_error(void) { return error_buffer(); }
 extern "C" int adcdiff_groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const float* gamma, const float* beta,
                                       float eps, int out_dtype, void* out, int ldo, void* raw_out, int ldraw,
                                       adcdiff_stream_t stream) {
-    return groupnorm_silu(x, ldx, M, C, groups, gamma, beta, eps, out_dtype, out, ldo, raw_out, ldraw, as_stream(stream));
+    return groupnorm_silu(x, ldx, M, C, groups, gamma, beta, eps, out_dtype, out, ldo, raw_out, ldraw, as_stream(stream), 0.0f, 0, 0);
 }
 
 extern "C" int adcdiff_philox_normal(float* out, int ld, int rows, int cols, uint64_t seed, uint32_t stream_id, uint32_t step,

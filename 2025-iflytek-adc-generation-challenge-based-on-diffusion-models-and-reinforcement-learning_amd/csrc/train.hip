@@ -1,0 +1,419 @@
+// Training step of the denoiser: forward with saved activations, noise-prediction loss, and the backward
+// pass (diffusion_model.py:165-184 p_losses, :401-471 train_step) on the same MFMA GEMM as inference.
+//
+// Forward: the unfused path of unet.hip with a tape (float32 layer outputs stay in the workspace) and
+// training-mode dropout in the norm2 activation (counter RNG keyed by layer / row / column).
+// Backward of y = x W^T (+ b):   dX = dY W   is the NT GEMM  [dY] x [W^T stored (K, N)],
+//                                 dW = dY^T X is the NT GEMM  [dY^T stored (N, M)] x [X^T stored (K, M)],
+// so every Linear costs two GEMM launches plus transposes (cast_transpose_kernel, which also yields the bias
+// gradient as its column sums).  GroupNorm+SiLU(+dropout) backward recomputes the statistics from the saved
+// pre-norm tensor (gn_silu_bwd_kernel).  The time branch is differentiated through the per-timestep tables:
+// d(linear1 output) rows are scatter-added into d_tb_table[t_row], and the table-building GEMMs (M = T) are
+// back-propagated once per step.
+#include "unet_plan.h"
+
+namespace adcdiff {
+
+// ------------------------------------------------------------------ kernels
+// dst_rm[r, c] = (OutT) src[r, c] (r < rows), dst_t[c, r] = (OutT) src[r, c] with zeros for rows <= r < rows_pad,
+// colsum[c] += sum_r src[r, c].  64 x 64 tile per workgroup through LDS.
+template <typename InT, typename OutT>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const InT* __restrict__ src, long lds_, int rows, int rows_pad, int cols,
+                                                             OutT* __restrict__ dst_rm, long ldrm, OutT* __restrict__ dst_t, long ldt,
+                                                             float* __restrict__ colsum) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+    float csum = 0.0f;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i;
+        float v = 0.0f;
+        if (r < rows) {
+            v = (float)src[(long)r * lds_ + c0 + tx];
+            if (dst_rm) dst_rm[(long)r * ldrm + c0 + tx] = (OutT)v;
+        }
+        tile[i][tx] = v;
+        csum += v;
+    }
+    __syncthreads();
+    if (dst_t) {
+        for (int i = ty; i < 64; i += 4) {
+            const int r = r0 + tx;   // transposed: tx walks the source rows
+            if (r < rows_pad) dst_t[(long)(c0 + i) * ldt + r] = (OutT)tile[tx][i];
+        }
+    }
+    if (colsum) {
+        __syncthreads();
+        tile[ty][tx] = csum;     // rows 0..3 of the tile are free after the transpose reads
+        __syncthreads();
+        if (ty == 0) atomicAdd(colsum + c0 + tx, (tile[0][tx] + tile[1][tx]) + (tile[2][tx] + tile[3][tx]));
+    }
+}
+
+// Backward of a = dropout(SiLU(GroupNorm(u))) for 32 rows x 4 columns per thread:
+//   d_u = rstd * (dxh - mean_g(dxh) - xh * mean_g(dxh * xh)),  dxh = dA * keep * silu'(n) * gamma,  n = xh * gamma + beta
+//   dgamma[c] += sum_rows dA * keep * silu'(n) * xh,   dbeta[c] += sum_rows dA * keep * silu'(n)
+// dst = (accumulate ? dst : 0) + d_u + add.
+__global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* __restrict__ u, long ldu, const float* __restrict__ dA, long ldda,
+                                                          int rows, int c4, int lanes_per_group, float inv_gs,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          float drop_p, uint64_t drop_seed, uint32_t drop_layer, int drop_col0,
+                                                          const float* __restrict__ add, long ldadd, float* __restrict__ dst, long lddst,
+                                                          int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const bool col_live = q < c4;
+    const int col = (col_live ? q : 0) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + col);
+    f32x4 dg = {0, 0, 0, 0}, db = {0, 0, 0, 0};
+    const int rbeg = blockIdx.y * 32;
+    const int rend = rbeg + 32 < rows ? rbeg + 32 : rows;
+    for (int r = rbeg; r < rend; ++r) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(u + (long)r * ldu + col);
+        const f32x4 da = *reinterpret_cast<const f32x4*>(dA + (long)r * ldda + col);
+        float s = (x[0] + x[1]) + (x[2] + x[3]);
+        for (int m = 1; m < lanes_per_group; m <<= 1) s += __shfl_xor(s, m);
+        const float mean = s * inv_gs;
+        const f32x4 d = {x[0] - mean, x[1] - mean, x[2] - mean, x[3] - mean};
+        float v = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        for (int m = 1; m < lanes_per_group; m <<= 1) v += __shfl_xor(v, m);
+        const float rstd = 1.0f / __builtin_sqrtf(v * inv_gs + eps);
+        f32x4 keep = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (drop_p > 0.0f) keep = dropout_keep4(drop_seed, drop_layer, (uint64_t)r, (uint32_t)((drop_col0 + col) >> 2), drop_p);
+        f32x4 xh, dxh;
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xh[i] = d[i] * rstd;
+            const float n = xh[i] * g[i] + b[i];
+            const float sig = 1.0f / (1.0f + expf(-n));
+            const float dn = da[i] * keep[i] * (sig * (1.0f + n * (1.0f - sig)));
+            dg[i] += dn * xh[i];
+            db[i] += dn;
+            dxh[i] = dn * g[i];
+            s1 += dxh[i];
+            s2 += dxh[i] * xh[i];
+        }
+        for (int m = 1; m < lanes_per_group; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+        s1 *= inv_gs; s2 *= inv_gs;
+        if (col_live) {
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = rstd * (dxh[i] - s1 - xh[i] * s2);
+            if (add) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(add + (long)r * ldadd + col);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] += a[i];
+            }
+            float* dp = dst + (long)r * lddst + col;
+            if (accumulate) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(dp);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] += a[i];
+            }
+            *reinterpret_cast<f32x4*>(dp) = o;
+        }
+    }
+    if (col_live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { atomicAdd(dgamma + col + i, dg[i]); atomicAdd(dbeta + col + i, db[i]); }
+    }
+}
+
+// dx = dy * silu'(x), elementwise over [rows, cols] (all leading dimensions = cols).
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const float v = x[e];
+    const float sig = 1.0f / (1.0f + expf(-v));
+    dx[e] = dy[e] * (sig * (1.0f + v * (1.0f - sig)));
+}
+
+// table[t[r], col0 + c] += src[r, c]
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, long lds_, const int64_t* __restrict__ t, int rows,
+                                                               int cols, float* __restrict__ table, long ldt, int col0) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rows * cols) return;
+    const long r = e / cols;
+    const int c = (int)(e - r * cols);
+    atomicAdd(table + (long)t[r] * ldt + col0 + c, src[r * lds_ + c]);
+}
+
+// d_pred = 2 * scale * (pred - target) / n;  *loss += scale * sum((target - pred)^2) / n   (F.mse_loss, mean reduction)
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ pred, long ldp, const float* __restrict__ target, long ldt_,
+                                                       float* __restrict__ dpred, long ldd, int rows, int cols, float scale, float* loss) {
+    __shared__ float part[4];
+    const long n = (long)rows * cols;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    float sq = 0.0f;
+    if (e < n) {
+        const long r = e / cols;
+        const int c = (int)(e - r * cols);
+        const float d = pred[r * ldp + c] - target[r * ldt_ + c];
+        dpred[r * ldd + c] = 2.0f * scale * d / (float)n;
+        sq = d * d;
+    }
+    for (int m = 32; m > 0; m >>= 1) sq += __shfl_xor(sq, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, scale * ((part[0] + part[1]) + (part[2] + part[3])) / (float)n);
+}
+
+__global__ __launch_bounds__(256) void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, long n, int accumulate) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) dst[e] = (accumulate ? dst[e] : 0.0f) + src[e];
+}
+
+// ------------------------------------------------------------------ host helpers
+template <typename InT>
+static int cast_transpose(const InT* src, long lds_, int rows, int rows_pad, int cols, int out_dtype, void* dst_rm, long ldrm, void* dst_t,
+                          long ldt, float* colsum, hipStream_t st) {
+    if (cols % 64 != 0) return fail(ADCDIFF_E_BADARG, "cast_transpose: cols=%d must be a multiple of 64", cols);
+    const dim3 grid((unsigned)((rows_pad + 63) / 64), (unsigned)(cols / 64));
+    if (out_dtype == ADCDIFF_BF16)
+        hipLaunchKernelGGL((cast_transpose_kernel<InT, bf16_t>), grid, dim3(256), 0, st, src, lds_, rows, rows_pad, cols,
+                           reinterpret_cast<bf16_t*>(dst_rm), ldrm, reinterpret_cast<bf16_t*>(dst_t), ldt, colsum);
+    else
+        hipLaunchKernelGGL((cast_transpose_kernel<InT, float>), grid, dim3(256), 0, st, src, lds_, rows, rows_pad, cols,
+                           reinterpret_cast<float*>(dst_rm), ldrm, reinterpret_cast<float*>(dst_t), ldt, colsum);
+    return check_launch("cast_transpose");
+}
+
+// transposes an operand-typed [rows, cols] activation into [cols, rows_pad]
+static int transpose_op(const void* src, long lds_, int rows, int rows_pad, int cols, int dtype, void* dst_t, hipStream_t st) {
+    if (dtype == ADCDIFF_BF16)
+        return cast_transpose<bf16_t>(reinterpret_cast<const bf16_t*>(src), lds_, rows, rows_pad, cols, dtype, nullptr, 0, dst_t, rows_pad, nullptr, st);
+    return cast_transpose<float>(reinterpret_cast<const float*>(src), lds_, rows, rows_pad, cols, dtype, nullptr, 0, dst_t, rows_pad, nullptr, st);
+}
+
+static int gn_silu_bwd(const float* u, long ldu, const float* dA, long ldda, int rows, int C, int groups, const float* gamma,
+                       const float* beta, float drop_p, uint64_t drop_seed, uint32_t drop_layer, int drop_col0, const float* add,
+                       long ldadd, float* dst, long lddst, int accumulate, float* dgamma, float* dbeta, hipStream_t st) {
+    const int gs = C / groups;
+    if (gs < 4 || gs > 256 || (gs & (gs - 1)) != 0)
+        return fail(ADCDIFF_E_BADARG, "training needs GroupNorm groups that are powers of two in 4..256 (got %d)", gs);
+    const dim3 grid((unsigned)((C / 4 + 255) / 256), (unsigned)((rows + 31) / 32));
+    hipLaunchKernelGGL(gn_silu_bwd_kernel, grid, dim3(256), 0, st, u, ldu, dA, ldda, rows, C / 4, gs / 4, 1.0f / (float)gs, gamma, beta, 1e-5f,
+                       drop_p, drop_seed, drop_layer, drop_col0, add, ldadd, dst, lddst, accumulate, dgamma, dbeta);
+    return check_launch("gn_silu_bwd");
+}
+
+static int gemm_simple(int dt, const void* A, int lda, const void* W, int ldw, int M, int m_valid, int N, int K, float* out, int ldo,
+                       hipStream_t st) {
+    adcdiff_gemm_args g = gemm_args(dt, M, m_valid, N);
+    g.nseg = 1; g.A[0] = A; g.lda[0] = lda; g.K[0] = K; g.W = W; g.ldw = ldw; g.out_f32 = out; g.ldo_f32 = ldo;
+    return gemm_dispatch(g, st);
+}
+
+static int copy_f32(const float* src, float* dst, long n, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, accumulate);
+    return check_launch("copy_f32");
+}
+
+}  // namespace adcdiff
+
+using namespace adcdiff;
+
+static size_t train_forward_bytes(adcdiff_unet* n, int B) {
+    Bump ws(nullptr, 0);
+    forward_unfused(n, nullptr, 0, B, nullptr, 0, nullptr, 0, nullptr, 0, ws, true, nullptr);
+    return ws.off;
+}
+
+static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adcdiff_unet_grads* gr, int B, Bump& ws, bool dry, hipStream_t st);
+
+// Backward workspace = a dry run of the same allocation sequence.
+static size_t train_backward_bytes(adcdiff_unet* n, int B) {
+    static const adcdiff_unet_grads none{};
+    Bump ws(nullptr, 0);
+    backward_impl(n, nullptr, 0, &none, B, ws, true, nullptr);
+    return ws.off + 256;
+}
+
+extern "C" size_t adcdiff_unet_train_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int num_timesteps, int dtype, int batch) {
+    adcdiff_unet n{};
+    if (batch <= 0 || plan_dims(&n, input_dim, hidden_dim, output_dim, num_timesteps, dtype) != ADCDIFF_OK) return 0;
+    return train_forward_bytes(&n, batch) + train_backward_bytes(&n, batch);
+}
+
+extern "C" int adcdiff_unet_train_forward(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, float dropout_p,
+                                          uint64_t dropout_seed, float* eps, int lde, void* workspace, size_t workspace_bytes,
+                                          adcdiff_stream_t stream_) {
+    if (!n || !n->packed) return fail(ADCDIFF_E_BADARG, "unet_train_forward: plan missing or not packed");
+    if (!x || !eps || !t_rows || B <= 0 || ldx < n->D || lde < n->O || !aligned16(x) || !aligned16(eps) || ldx % 4 || lde % 4)
+        return fail(ADCDIFF_E_BADARG, "unet_train_forward: bad x / t / eps arguments");
+    if (dropout_p < 0.0f || dropout_p >= 1.0f) return fail(ADCDIFF_E_BADARG, "unet_train_forward: dropout probability %f", dropout_p);
+    if (!workspace || !aligned16(workspace)) return fail(ADCDIFF_E_BADARG, "unet_train_forward: workspace null or misaligned");
+    const size_t need = train_forward_bytes(n, B) + train_backward_bytes(n, B);
+    if (workspace_bytes < need) return fail(ADCDIFF_E_WORKSPACE, "unet_train_forward: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+    for (int i = 0; i < 10; ++i)
+        if (n->blk[i].cout % 128 != 0) return fail(ADCDIFF_E_BADARG, "training needs layer widths that are multiples of 128 (got %d)", n->blk[i].cout);
+    Bump ws(workspace, workspace_bytes);
+    n->tape = Tape{};
+    return forward_unfused(n, x, ldx, B, t_rows, 0, nullptr, 0, eps, lde, ws, false, as_stream(stream_), &n->tape, dropout_p, dropout_seed);
+}
+
+extern "C" int adcdiff_mse_loss_grad(const float* pred, int ldp, const float* target, int ldt, float* dpred, int ldd, int B, int D,
+                                     float scale, float* loss_accum, adcdiff_stream_t stream_) {
+    if (!pred || !target || !dpred || !loss_accum || B <= 0 || D <= 0 || ldp < D || ldt < D || ldd < D)
+        return fail(ADCDIFF_E_BADARG, "mse_loss_grad: bad arguments");
+    const long nel = (long)B * D;
+    hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, as_stream(stream_), pred, (long)ldp, target, (long)ldt,
+                       dpred, (long)ldd, B, D, scale, loss_accum);
+    return check_launch("mse_loss_grad");
+}
+
+extern "C" int adcdiff_unet_backward(adcdiff_unet* n, const float* d_eps, int lde, const adcdiff_unet_grads* gr, void* workspace,
+                                     size_t workspace_bytes, adcdiff_stream_t stream_) {
+    if (!n || !n->tape.valid) return fail(ADCDIFF_E_BADARG, "unet_backward: no training forward recorded on this plan");
+    if (!d_eps || !gr || lde < n->O) return fail(ADCDIFF_E_BADARG, "unet_backward: bad arguments");
+    const size_t fwd = round_up(n->tape.ws_used, 256);
+    if (workspace_bytes < fwd + train_backward_bytes(n, n->tape.B)) return fail(ADCDIFF_E_WORKSPACE, "unet_backward: workspace too small");
+    Bump ws(reinterpret_cast<char*>(workspace) + fwd, workspace_bytes - fwd);
+    return backward_impl(n, d_eps, lde, gr, n->tape.B, ws, false, as_stream(stream_));
+}
+
+#define RUN(expr) do { if (!dry) TRY(expr); } while (0)
+
+static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adcdiff_unet_grads* gr, int B, Bump& ws, bool dry, hipStream_t st) {
+    const Tape& tp = n->tape;
+    const int Bp = (int)round_up((size_t)B, 128), dt = n->dtype, H = n->H, O = n->O, Tp = n->Tp, SN = n->sumN;
+    const size_t e = (size_t)n->esz;
+    const adcdiff_unet_params& p = n->prm;
+
+    // gradients of the block outputs, and of the per-timestep table
+    float* dO[10];
+    bool dO_written[10];
+    for (int i = 0; i < 10; ++i) { dO[i] = (float*)ws.take((size_t)Bp * n->blk[i].cout * 4); dO_written[i] = false; }
+    float* d_tb = (float*)ws.take((size_t)Tp * SN * 4);
+    if (!dry && hipMemsetAsync(d_tb, 0, (size_t)Tp * SN * 4, st) != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "unet_backward: memset failed");
+
+    // ---- output head: eps = out_layer(a_out), a_out = SiLU(output_norm(o9)) (diffusion_model.py:786-788)
+    {
+        void* dE_rm = ws.take((size_t)Bp * O * e);
+        void* dE_t = ws.take((size_t)O * Bp * e);
+        RUN(cast_transpose<float>(d_eps, lde, B, Bp, O, dt, dE_rm, O, dE_t, Bp, gr->out_b, st));
+        void* aT = ws.take((size_t)H * Bp * e);
+        RUN(transpose_op(tp.a_out, H, B, Bp, H, dt, aT, st));
+        RUN(gemm_simple(dt, dE_t, Bp, aT, Bp, O, 0, H, Bp, gr->out_w, H, st));
+        void* wT = ws.take((size_t)H * O * e);
+        RUN(cast_transpose<float>(p.out_w, H, O, O, H, dt, nullptr, 0, wT, O, nullptr, st));
+        float* d_a = (float*)ws.take((size_t)Bp * H * 4);
+        RUN(gemm_simple(dt, dE_rm, O, wT, O, Bp, B, H, O, d_a, H, st));
+        RUN(gn_silu_bwd(tp.blk[9].o, n->blk[9].cout, d_a, H, B, H, num_groups(H), p.out_norm_w, p.out_norm_b, 0.0f, 0, 0, 0, nullptr, 0, dO[9],
+                        n->blk[9].cout, 0, gr->out_norm_w, gr->out_norm_b, st));
+        dO_written[9] = true;
+    }
+    const size_t mark = ws.off;
+    for (int i = 9; i >= 0; --i) {
+        ws.off = mark;   // per-block temporaries are reused
+        const BlockPlan& b = n->blk[i];
+        const BlockTape& bt = tp.blk[i];
+        const adcdiff_block_params& q = p.blocks[i];
+        const adcdiff_block_grads& g = gr->blocks[i];
+        const int cin = b.cin, cout = b.cout;
+        // (1) dO in the operand type, row-major and transposed; its column sums are d(linear2.bias) (= d(residual_proj.bias))
+        void* dO_rm = ws.take((size_t)Bp * cout * e);
+        void* dO_t = ws.take((size_t)cout * Bp * e);
+        RUN(cast_transpose<float>(dO[i], cout, B, Bp, cout, dt, dO_rm, cout, dO_t, Bp, g.linear2_b, st));
+        if (b.has_res) RUN(copy_f32(g.linear2_b, g.residual_b, cout, 0, st));
+        // (2) d(linear2.weight) = dO^T a2
+        void* xT = ws.take((size_t)(cin > cout ? cin : cout) * Bp * e);
+        RUN(transpose_op(bt.a2, cout, B, Bp, cout, dt, xT, st));
+        RUN(gemm_simple(dt, dO_t, Bp, xT, Bp, cout, 0, cout, Bp, g.linear2_w, cout, st));
+        // (3) residual_proj: d(weight) = dO^T x, d(x) = dO Wres
+        float* d_raw = nullptr;
+        void* wT = ws.take((size_t)(cin > cout ? cin : cout) * cout * e);
+        if (b.has_res) {
+            int row0 = 0;
+            for (int k = 0; k < b.nparts; ++k) {
+                RUN(transpose_op(bt.in_raw[k], b.part_c[k], B, Bp, b.part_c[k], dt, (char*)xT + (size_t)row0 * Bp * e, st));
+                row0 += b.part_c[k];
+            }
+            RUN(gemm_simple(dt, dO_t, Bp, xT, Bp, cout, 0, cin, Bp, g.residual_w, cin, st));
+            RUN(cast_transpose<float>(q.residual_w, cin, cout, cout, cin, dt, nullptr, 0, wT, cout, nullptr, st));
+            d_raw = (float*)ws.take((size_t)Bp * cin * 4);
+            RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cin, cout, d_raw, cin, st));
+        }
+        // (4) d(a2) = dO W2; (5) through dropout, SiLU and norm2 to d(h1)
+        RUN(cast_transpose<float>(q.linear2_w, cout, cout, cout, cout, dt, nullptr, 0, wT, cout, nullptr, st));
+        float* d_a2 = (float*)ws.take((size_t)Bp * cout * 4);
+        RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cout, cout, d_a2, cout, st));
+        float* d_h1 = (float*)ws.take((size_t)Bp * cout * 4);
+        RUN(gn_silu_bwd(bt.h1, cout, d_a2, cout, B, cout, b.g2, q.norm2_w, q.norm2_b, tp.drop_p, tp.drop_seed, (uint32_t)i, 0, nullptr, 0, d_h1,
+                        cout, 0, g.norm2_w, g.norm2_b, st));
+        // (6) d(h1): column sums are d(linear1.bias) = d(time_proj.bias); (7) rows go to the timestep table
+        RUN(cast_transpose<float>(d_h1, cout, B, Bp, cout, dt, dO_rm, cout, dO_t, Bp, g.linear1_b, st));
+        RUN(copy_f32(g.linear1_b, g.time_proj_b, cout, 0, st));
+        {
+            const long total = (long)B * cout;
+            if (!dry) {
+                hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_h1, (long)cout, tp.t_rows, B,
+                                   cout, d_tb, (long)SN, b.tb_off);
+                TRY(check_launch("scatter_add_rows"));
+            }
+        }
+        // (8) d(linear1.weight) = d_h1^T a1; (9) d(a1) = d_h1 W1
+        RUN(transpose_op(bt.a1, cin, B, Bp, cin, dt, xT, st));
+        RUN(gemm_simple(dt, dO_t, Bp, xT, Bp, cout, 0, cin, Bp, g.linear1_w, cin, st));
+        RUN(cast_transpose<float>(q.linear1_w, cin, cout, cout, cin, dt, nullptr, 0, wT, cout, nullptr, st));
+        float* d_a1 = (float*)ws.take((size_t)Bp * cin * 4);
+        RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cin, cout, d_a1, cin, st));
+        // (10) through SiLU and norm1 of each input part; the result plus the residual-path gradient is the gradient of the
+        // tensor that part came from (previous block, or the encoder output of a skip connection)
+        float* scratch = (float*)ws.take((size_t)Bp * b.part_c[0] * 4);
+        int col = 0;
+        for (int k = 0; k < b.nparts; ++k) {
+            const int src = k == 0 ? i - 1 : 9 - i;    // producer of this part (-1: the network input)
+            float* dst = src >= 0 ? dO[src] : scratch;
+            const int lddst = b.part_c[k];
+            const int acc = src >= 0 && dO_written[src] ? 1 : 0;
+            const float* add = b.has_res ? d_raw + col : dO[i];     // Identity residual passes dO straight through
+            const long ldadd = b.has_res ? cin : cout;
+            RUN(gn_silu_bwd(bt.in_f32[k], bt.in_ld[k], d_a1 + col, cin, B, b.part_c[k], b.part_c[k] / b.gs1, q.norm1_w + col, q.norm1_b + col, 0.0f,
+                            0, 0, 0, add, ldadd, dst, lddst, acc, g.norm1_w + col, g.norm1_b + col, st));
+            if (src >= 0) dO_written[src] = true;
+            col += b.part_c[k];
+        }
+    }
+    // ---- time branch: tb_table = SiLU(te_table) Wtp_all^T + btp_all; te_table = te_hidden W2^T + b2; te_hidden = SiLU(te_pre);
+    //      te_pre = sinusoid W1^T + b1 (all float32, M = Tp rows of which only the drawn timesteps carry gradient)
+    ws.off = mark;
+    {
+        float* dTB_t = (float*)ws.take((size_t)SN * Tp * 4);
+        RUN(cast_transpose<float>(d_tb, SN, Tp, Tp, SN, ADCDIFF_F32, nullptr, 0, dTB_t, Tp, nullptr, st));
+        float* sT = (float*)ws.take((size_t)H * Tp * 4);
+        RUN(cast_transpose<float>(n->s_table, H, Tp, Tp, H, ADCDIFF_F32, nullptr, 0, sT, Tp, nullptr, st));
+        for (int i = 0; i < 10; ++i)
+            RUN(gemm_simple(ADCDIFF_F32, dTB_t + (size_t)n->blk[i].tb_off * Tp, Tp, sT, Tp, n->blk[i].cout, 0, H, Tp, gr->blocks[i].time_proj_w, H, st));
+        float* wtpT = (float*)ws.take((size_t)H * SN * 4);
+        RUN(cast_transpose<float>(n->wtp_all, H, SN, SN, H, ADCDIFF_F32, nullptr, 0, wtpT, SN, nullptr, st));
+        float* d_s = (float*)ws.take((size_t)Tp * H * 4);
+        RUN(gemm_simple(ADCDIFF_F32, d_tb, SN, wtpT, SN, Tp, 0, H, SN, d_s, H, st));
+        float* d_te = (float*)ws.take((size_t)Tp * H * 4);
+        if (!dry) {
+            hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)(((long)Tp * H + 255) / 256)), dim3(256), 0, st, n->te_table, d_s, d_te, (long)Tp * H);
+            TRY(check_launch("silu_bwd"));
+        }
+        float* dTE_t = (float*)ws.take((size_t)H * Tp * 4);
+        RUN(cast_transpose<float>(d_te, H, Tp, Tp, H, ADCDIFF_F32, nullptr, 0, dTE_t, Tp, gr->time_lin2_b, st));
+        float* hidT = (float*)ws.take((size_t)4 * H * Tp * 4);
+        RUN(cast_transpose<float>(n->te_hidden, 4 * H, Tp, Tp, 4 * H, ADCDIFF_F32, nullptr, 0, hidT, Tp, nullptr, st));
+        RUN(gemm_simple(ADCDIFF_F32, dTE_t, Tp, hidT, Tp, H, 0, 4 * H, Tp, gr->time_lin2_w, 4 * H, st));
+        float* w2T = (float*)ws.take((size_t)4 * H * H * 4);
+        RUN(cast_transpose<float>(p.time_lin2_w, 4 * H, H, H, 4 * H, ADCDIFF_F32, nullptr, 0, w2T, H, nullptr, st));
+        float* d_hid = (float*)ws.take((size_t)Tp * 4 * H * 4);
+        RUN(gemm_simple(ADCDIFF_F32, d_te, H, w2T, H, Tp, 0, 4 * H, H, d_hid, 4 * H, st));
+        float* d_pre = (float*)ws.take((size_t)Tp * 4 * H * 4);
+        if (!dry) {
+            hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)(((long)Tp * 4 * H + 255) / 256)), dim3(256), 0, st, n->te_pre, d_hid, d_pre, (long)Tp * 4 * H);
+            TRY(check_launch("silu_bwd"));
+        }
+        float* dPRE_t = (float*)ws.take((size_t)4 * H * Tp * 4);
+        RUN(cast_transpose<float>(d_pre, 4 * H, Tp, Tp, 4 * H, ADCDIFF_F32, nullptr, 0, dPRE_t, Tp, gr->time_lin1_b, st));
+        float* sinT = (float*)ws.take((size_t)H * Tp * 4);
+        RUN(cast_transpose<float>(n->sin_table, H, Tp, Tp, H, ADCDIFF_F32, nullptr, 0, sinT, Tp, nullptr, st));
+        RUN(gemm_simple(ADCDIFF_F32, dPRE_t, Tp, sinT, Tp, 4 * H, 0, H, Tp, gr->time_lin1_w, H, st));
+    }
+    return ADCDIFF_OK;
+}

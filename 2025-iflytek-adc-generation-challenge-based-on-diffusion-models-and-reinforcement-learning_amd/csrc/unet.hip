@@ -1,81 +1,8 @@
-// Host-side plan of the denoiser (UNetModel.forward, diffusion_model.py:749-789) and of the reverse
-// loops over the kernels of gemm.hip / elementwise.hip.  Nothing here allocates device memory: packed
-// weights and timestep tables live in the caller's arena, activations in the caller's workspace, both
-// carved by a bump allocator whose dry run gives the sizes reported to the caller.
-//
-// Per ResidualBlock (diffusion_model.py:875-907) two GEMM launches and nothing else; every GroupNorm+SiLU
-// is applied by the GEMM that PRODUCES its input, from the float32 accumulators, so each tensor is
-// written once in the forms its consumers need and never re-read to be normalised:
-//   GEMM1: a2 = SiLU(GroupNorm2([n_in | s] * [W1 | Wtp]^T + b1 (+ table[t])))
-//          n_in = the already normalised input part(s) (cat([h, skip]) is two K segments, never a copy);
-//          the time_proj term is a per-timestep table row when unconditional and an extra K segment
-//          s = SiLU(t_emb + c_emb) when a condition makes it row dependent
-//   GEMM2: o = [a2 | raw_in] * [W2 | Wres]^T + b2 + bres   (Identity residual: + raw_in in the epilogue)
-//          stored as raw_o (operand type: the next residual operand) and as SiLU(GroupNorm(o)) under the
-//          norm1 of the next block and, for encoder outputs, under the decoder's norm1 slice of the skip
-// Dimensions whose GroupNorm groups are not powers of two in 4..128 take the unfused path (float32 layer
-// outputs, stand-alone groupnorm_silu kernels), which has no such restriction.
-#include <cstring>
-#include <new>
-
-#include "common.h"
-
-namespace adcdiff {
-
-int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream);
-int groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const float* gamma, const float* beta, float eps,
-                   int out_dtype, void* out, int ldo, void* raw_out, int ldraw, hipStream_t stream);
-int sinusoid_table(float* out, int ld, int rows, int half, const float* freq, hipStream_t stream);
-int temb_silu(const float* te_table, int ldt, const int64_t* t_rows, int t_uniform, const float* cemb, int ldce, int dtype,
-              void* out, int ldo, int rows, int H, hipStream_t stream);
-int cast_pack(const float* src, int lds_, int dtype, void* dst, int ldd, int col0, int rows, int cols, hipStream_t stream);
-int add_vec(const float* a, const float* b, float* out, int n, hipStream_t stream);
-
-static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-static int num_groups(int dim) {   // diffusion_model.py:723-730, 840-847
-    if (dim < 4) return 1;
-    for (int g = dim < 32 ? dim : 32; g > 0; --g)
-        if (dim % g == 0) return g;
-    return 1;
-}
-
-struct Bump {
-    char* base;
-    size_t off = 0, cap;
-    Bump(void* b, size_t c) : base(reinterpret_cast<char*>(b)), cap(c) {}
-    void* take(size_t bytes) {
-        void* p = base + off;   // in a dry run base is null and only `off` matters
-        off += round_up(bytes, 256);
-        return p;
-    }
-};
-
-struct BlockPlan {
-    int cin, cout, nparts, part_c[2];
-    bool has_res;
-    int g1, g2, tb_off, ldw1, ldw2;
-    void *w1cat, *w2cat;
-    float *bias1, *bias1_cond, *bias2;
-    int gs1, gs2;   // channels per GroupNorm group of norm1 (over the whole concatenated input) and norm2
-};
-
-}  // namespace adcdiff
+#include "unet_plan.h"
 
 using namespace adcdiff;
 
-struct adcdiff_unet {
-    adcdiff_unet_params prm;
-    int dtype, esz, D, H, O, T, Tp, sumN;
-    BlockPlan blk[10];
-    float *sin_table, *te_hidden, *te_table, *s_table, *wtp_all, *btp_all, *tb_table;
-    void *w_out, *w_c0, *w_c2;
-    size_t arena_used;
-    bool packed;
-    bool fused;     // every GroupNorm can be applied in a producing GEMM's epilogue
-};
-
-static int plan_dims(adcdiff_unet* n, int input_dim, int hidden_dim, int output_dim, int num_timesteps, int dtype) {
+int adcdiff::plan_dims(adcdiff_unet* n, int input_dim, int hidden_dim, int output_dim, int num_timesteps, int dtype) {
     if (dtype != ADCDIFF_F32 && dtype != ADCDIFF_BF16) return fail(ADCDIFF_E_BADARG, "unet: unknown dtype %d", dtype);
     if (input_dim <= 0 || hidden_dim <= 0 || output_dim <= 0 || input_dim % 64 || hidden_dim % 64 || output_dim % 64)
         return fail(ADCDIFF_E_BADARG, "unet: input_dim=%d hidden_dim=%d output_dim=%d must be positive multiples of 64", input_dim,
@@ -131,6 +58,7 @@ static void carve_arena(adcdiff_unet* n, void* arena, size_t cap) {
     n->w_c0 = a.take((size_t)n->H * n->D * e);
     n->w_c2 = a.take((size_t)n->H * n->H * e);
     n->sin_table = (float*)a.take((size_t)n->Tp * n->H * 4);
+    n->te_pre = (float*)a.take((size_t)n->Tp * 4 * n->H * 4);
     n->te_hidden = (float*)a.take((size_t)n->Tp * 4 * n->H * 4);
     n->te_table = (float*)a.take((size_t)n->Tp * n->H * 4);
     n->s_table = (float*)a.take((size_t)n->Tp * n->H * 4);
@@ -188,9 +116,7 @@ extern "C" int adcdiff_unet_create(const adcdiff_unet_params* p, int dtype, void
 
 extern "C" void adcdiff_unet_destroy(adcdiff_unet* n) { delete n; }
 
-#define TRY(expr) do { int rc_ = (expr); if (rc_ != ADCDIFF_OK) return rc_; } while (0)
-
-static adcdiff_gemm_args gemm_args(int dtype, int M, int m_valid, int N) {
+adcdiff_gemm_args adcdiff::gemm_args(int dtype, int M, int m_valid, int N) {
     adcdiff_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.dtype = dtype; g.M = M; g.m_valid = m_valid; g.N = N;
@@ -224,8 +150,9 @@ extern "C" int adcdiff_unet_pack(adcdiff_unet* n, void* workspace, size_t worksp
     TRY(sinusoid_table(n->sin_table, H, n->Tp, H / 2, p.sinusoid_freq, st));
     adcdiff_gemm_args g = gemm_args(ADCDIFF_F32, n->Tp, 0, 4 * H);
     g.nseg = 1; g.A[0] = n->sin_table; g.lda[0] = H; g.K[0] = H; g.W = p.time_lin1_w; g.ldw = H; g.bias = p.time_lin1_b;
-    g.act = 1; g.out_f32 = n->te_hidden; g.ldo_f32 = 4 * H;
+    g.out_f32 = n->te_pre; g.ldo_f32 = 4 * H;   // pre-activation kept for the training step's backward
     TRY(gemm_dispatch(g, st));
+    TRY(temb_silu(n->te_pre, 4 * H, nullptr, -1, nullptr, 0, ADCDIFF_F32, n->te_hidden, 4 * H, n->Tp, 4 * H, st));
     g = gemm_args(ADCDIFF_F32, n->Tp, 0, H);
     g.nseg = 1; g.A[0] = n->te_hidden; g.lda[0] = 4 * H; g.K[0] = 4 * H; g.W = p.time_lin2_w; g.ldw = 4 * H; g.bias = p.time_lin2_b;
     g.out_f32 = n->te_table; g.ldo_f32 = H;
@@ -249,8 +176,11 @@ struct Part {
 };
 
 // One denoiser forward.  With dry = true nothing is launched and only the bump offset advances.
-int forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform, const float* cemb,
-                 int ldce, float* eps, int lde, Bump& ws, bool dry, hipStream_t st) {
+}  // namespace
+
+int adcdiff::forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform, const float* cemb,
+                             int ldce, float* eps, int lde, Bump& ws, bool dry, hipStream_t st, Tape* tape, float drop_p,
+                             uint64_t drop_seed) {
     const int Bp = (int)round_up((size_t)B, 128);
     const size_t e = (size_t)n->esz;
     const int H = n->H, dt = n->dtype;
@@ -275,6 +205,7 @@ int forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, const int64
             cur[1] = outs[9 - i];
             ncur = 2;
         }
+        BlockTape* bt = tape ? &tape->blk[i] : nullptr;
         // a1 = SiLU(GroupNorm1(input)), written as one [Bp, cin] operand
         char* a1 = (char*)ws.take((size_t)Bp * b.cin * e);
         const int gs = b.cin / b.g1;
@@ -286,8 +217,10 @@ int forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, const int64
                 TRY(groupnorm_silu(cur[k].f32, cur[k].ld, B, cur[k].C, cur[k].C / gs, q.norm1_w + col, q.norm1_b + col, 1e-5f, dt,
                                    a1 + (size_t)col * e, b.cin, raw, cur[k].C, st));
             if (raw) cur[k].raw = raw;
+            if (bt) { bt->in_f32[k] = cur[k].f32; bt->in_ld[k] = cur[k].ld; bt->in_c[k] = cur[k].C; bt->in_raw[k] = cur[k].raw; }
             col += cur[k].C;
         }
+        if (bt) { bt->nparts = ncur; bt->a1 = a1; }
         // h1 = linear1(a1) + time_proj(SiLU(t_emb))
         float* h1 = (float*)ws.take((size_t)Bp * b.cout * 4);
         if (!dry) {
@@ -307,7 +240,9 @@ int forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, const int64
         }
         // a2 = SiLU(GroupNorm2(h1)); dropout is the identity in eval mode (diffusion_model.py:896-898)
         void* a2 = ws.take((size_t)Bp * b.cout * e);
-        if (!dry) TRY(groupnorm_silu(h1, b.cout, B, b.cout, b.g2, q.norm2_w, q.norm2_b, 1e-5f, dt, a2, b.cout, nullptr, 0, st));
+        // in a training forward the dropout of diffusion_model.py:898 is applied here (counter RNG keyed by layer and row)
+        if (!dry) TRY(groupnorm_silu(h1, b.cout, B, b.cout, b.g2, q.norm2_w, q.norm2_b, 1e-5f, dt, a2, b.cout, nullptr, 0, st, drop_p, drop_seed, (uint32_t)i));
+        if (bt) { bt->h1 = h1; bt->a2 = a2; }
         // o = linear2(a2) + residual_proj(input)
         float* o = (float*)ws.take((size_t)Bp * b.cout * 4);
         if (!dry) {
@@ -325,6 +260,7 @@ int forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, const int64
             g.out_f32 = o; g.ldo_f32 = b.cout;
             TRY(gemm_dispatch(g, st));
         }
+        if (bt) bt->o = o;
         // in float32 the block output is its own GEMM operand (padded rows included)
         outs[i] = Part{o, b.cout, b.cout, dt == ADCDIFF_F32 ? (const void*)o : nullptr};
         if (i >= 1 && i <= 4 && cur[0].raw) outs[i - 1].raw = cur[0].raw;   // keep the converted copy of a skip tensor
@@ -333,6 +269,10 @@ int forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, const int64
     }
     // output head: Linear(SiLU(GroupNorm(h))) (diffusion_model.py:786-788)
     void* a = ws.take((size_t)Bp * H * e);
+    if (tape) {
+        tape->a_out = a; tape->B = B; tape->t_rows = t_rows; tape->drop_p = drop_p; tape->drop_seed = drop_seed;
+        tape->valid = !dry;
+    }
     if (!dry) {
         TRY(groupnorm_silu(cur[0].f32, cur[0].ld, B, H, num_groups(H), p.out_norm_w, p.out_norm_b, 1e-5f, dt, a, H, nullptr, 0, st));
         adcdiff_gemm_args g = gemm_args(dt, Bp, B, n->O);
@@ -340,8 +280,11 @@ int forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, const int64
         g.out_f32 = eps; g.ldo_f32 = lde;
         TRY(gemm_dispatch(g, st));
     }
+    if (tape) tape->ws_used = ws.off;
     return ADCDIFF_OK;
 }
+
+namespace {
 
 // The fused path (see the header comment).  Activations are kept only in the operand type.
 struct Act {

@@ -199,6 +199,16 @@ class _Engine:
             self.version = version
         return self.handle
 
+    def train_workspace_for(self, batch, device):
+        m = self.model
+        need = self.lib.adcdiff_unet_train_workspace_bytes(m.input_dim, m.hidden_dim, m.output_dim, m.num_timesteps, self.dtype, batch)
+        if need == 0:
+            raise AdcdiffError(self.lib.adcdiff_last_error().decode())
+        if self.workspace is None or self.workspace.numel() < need or self.workspace.device != device:
+            self.workspace = None
+            self.workspace = torch.empty(need, device=device, dtype=torch.uint8)
+        return C.c_void_p(self.workspace.data_ptr()), self.workspace.numel()
+
     def workspace_for(self, batch, device):
         m = self.model
         need = self.lib.adcdiff_unet_workspace_bytes(m.input_dim, m.hidden_dim, m.output_dim, self.dtype, batch)
@@ -208,6 +218,70 @@ class _Engine:
             self.workspace = None
             self.workspace = torch.empty(need, device=device, dtype=torch.uint8)
         return C.c_void_p(self.workspace.data_ptr()), self.workspace.numel()
+
+
+def _grad_slots(model):
+    """(parameter, attribute path into _lib.UnetGrads) for every parameter the backward kernels produce a gradient for."""
+    slots = [(model.time_embed.linear1.weight, ("time_lin1_w",)), (model.time_embed.linear1.bias, ("time_lin1_b",)),
+             (model.time_embed.linear2.weight, ("time_lin2_w",)), (model.time_embed.linear2.bias, ("time_lin2_b",))]
+    for i, b in enumerate(list(model.encoder) + list(model.middle) + list(model.decoder)):
+        slots += [(b.norm1.weight, (i, "norm1_w")), (b.norm1.bias, (i, "norm1_b")), (b.norm2.weight, (i, "norm2_w")),
+                  (b.norm2.bias, (i, "norm2_b")), (b.linear1.weight, (i, "linear1_w")), (b.linear1.bias, (i, "linear1_b")),
+                  (b.linear2.weight, (i, "linear2_w")), (b.linear2.bias, (i, "linear2_b")),
+                  (b.time_proj[1].weight, (i, "time_proj_w")), (b.time_proj[1].bias, (i, "time_proj_b"))]
+        if isinstance(b.residual_proj, nn.Linear):
+            slots += [(b.residual_proj.weight, (i, "residual_w")), (b.residual_proj.bias, (i, "residual_b"))]
+    slots += [(model.output_norm.weight, ("out_norm_w",)), (model.output_norm.bias, ("out_norm_b",)),
+              (model.output_layer.weight, ("out_w",)), (model.output_layer.bias, ("out_b",))]
+    return slots
+
+
+class _NoisePredictionLoss(torch.autograd.Function):
+    """mse_loss(noise, UNet(x_noisy, t)) with the denoiser's forward AND backward in the HIP library
+    (adcdiff_unet_train_forward / adcdiff_mse_loss_grad / adcdiff_unet_backward).  The parameters enter as inputs
+    only so that autograd routes the library's gradients to them."""
+
+    @staticmethod
+    def forward(ctx, model, x_noisy, t, noise, dropout_p, dropout_seed, *params):
+        dev = model._device()
+        eng = model.engine()
+        handle = eng.ensure(dev)
+        B = x_noisy.shape[0]
+        ws, ws_bytes = eng.train_workspace_for(B, dev)
+        eps = torch.empty((B, model.output_dim), device=dev, dtype=torch.float32)
+        check(eng.lib.adcdiff_unet_train_forward(handle, ops._ptr(x_noisy), x_noisy.stride(0), B, ops._ptr(t), float(dropout_p),
+                                                 int(dropout_seed), ops._ptr(eps), model.output_dim, ws, ws_bytes, ops._stream()))
+        loss = torch.zeros((), device=dev, dtype=torch.float32)
+        d_eps = torch.empty_like(eps)
+        check(eng.lib.adcdiff_mse_loss_grad(ops._ptr(eps), model.output_dim, ops._ptr(noise), noise.stride(0), ops._ptr(d_eps),
+                                            model.output_dim, B, model.output_dim, 1.0, ops._ptr(loss), ops._stream()))
+        ctx.model, ctx.eng, ctx.handle, ctx.d_eps, ctx.t = model, eng, handle, d_eps, t
+        ctx.ws = (ws, ws_bytes)
+        ctx.version = eng._param_version()
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model, eng = ctx.model, ctx.eng
+        if eng._param_version() != ctx.version or eng.handle is None or eng.handle.value != ctx.handle.value:
+            raise AdcdiffError("parameters changed between the training forward and backward")
+        params = list(model.parameters())
+        slots = _grad_slots(model)
+        total = sum(p.numel() for p, _ in slots)
+        flat = torch.zeros(total + 4 * len(slots), device=ctx.d_eps.device, dtype=torch.float32)
+        grads = _lib.UnetGrads()
+        by_param = {}
+        off = 0
+        for p, path in slots:
+            g = flat[off:off + p.numel()].view_as(p)
+            off += (p.numel() + 3) // 4 * 4      # keep every gradient 16-byte aligned
+            by_param[id(p)] = g
+            target = grads if len(path) == 1 else grads.blocks[path[0]]
+            setattr(target, path[-1], g.data_ptr())
+        ws, ws_bytes = ctx.ws
+        check(eng.lib.adcdiff_unet_backward(ctx.handle, ops._ptr(ctx.d_eps), model.output_dim, C.byref(grads), ws, ws_bytes, ops._stream()))
+        flat.mul_(grad_out)
+        return (None, None, None, None, None, None) + tuple(by_param.get(id(p)) for p in params)
 
 
 class UNetModel(nn.Module):
@@ -435,13 +509,21 @@ class DiffusionModel(nn.Module):
 
     def p_losses(self, x_start: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None,
                  noise: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """diffusion_model.py:165-184 (forward value; the training step is not built on this path yet)."""
+        """diffusion_model.py:165-184.  With gradients enabled the returned loss back-propagates through the HIP
+        backward kernels (unconditional, as in the reference's train_step); otherwise only the value is computed."""
         dv = self._device_tables()
         x_noisy, used = ops.q_sample(x_start.to(torch.float32).contiguous(), t.to(torch.int64).contiguous(), dv["sqrt_ac"],
                                      dv["sqrt_1mac"], noise=noise.contiguous() if noise is not None else None,
                                      seed=_seed_from_torch() if noise is None else 0, return_noise=True)
-        predicted_noise = self.model(x_noisy, t, condition)
-        return F.mse_loss(used, predicted_noise)
+        wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters())
+        if not wants_grad:
+            predicted_noise = self.model(x_noisy, t, condition)
+            return F.mse_loss(used, predicted_noise)
+        if condition is not None:
+            raise NotImplementedError("the backward kernels cover the unconditional loss of train_step; a condition has no gradient path yet")
+        drop_p = self.model.encoder[0].dropout.p if self.model.training else 0.0
+        return _NoisePredictionLoss.apply(self.model, x_noisy, t.to(torch.int64).contiguous(), used, drop_p,
+                                          _seed_from_torch() if drop_p > 0 else 0, *self.model.parameters())
 
     # ---- reverse process --------------------------------------------------------------------
     def p_sample(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None,
@@ -572,9 +654,43 @@ class DiffusionModel(nn.Module):
 
     # ---- training -----------------------------------------------------------------------------
     def train_step(self, x: torch.Tensor, step: int = 0) -> Dict[str, float]:
-        """diffusion_model.py:401-471.  The backward kernels of the denoiser are not built yet, so this
-        raises instead of silently running a PyTorch implementation."""
-        raise NotImplementedError("train_step needs the denoiser's backward HIP kernels, which are not built yet")
+        """diffusion_model.py:401-471: random timesteps, noise-prediction loss, backward, clip_grad_norm_(1.0), optimizer step,
+        with the reference's gradient accumulation and chunking above max_batch_size.  Forward and backward of the denoiser
+        run in the HIP library; gradient clipping and AdamW are torch's (the optimizer object and its state_dict are part
+        of the reference's checkpoint format)."""
+        self.operation_count += 1
+        self.model.train()
+        batch_size = x.shape[0]
+        if batch_size > self.max_batch_size:
+            return self._train_step_chunked(x, step)
+        x = x.to(self.device)
+        t = torch.randint(0, self.num_timesteps, (batch_size,), device=self.device)
+        loss = self.p_losses(x, t)
+        loss = loss / self.gradient_accumulation_steps
+        loss.backward()
+        if (step + 1) % self.gradient_accumulation_steps == 0:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=1.0)
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+        memory_info = self._get_memory_usage()
+        return {
+            'loss': loss.item() * self.gradient_accumulation_steps,
+            'lr': self.optimizer.param_groups[0]['lr'],
+            'gpu_memory': memory_info.get('gpu_memory_used_gb', 0),
+            'gpu_memory_percent': memory_info.get('gpu_memory_percent', 0),
+            'system_memory_percent': memory_info.get('system_memory_percent', 0),
+        }
+
+    def _train_step_chunked(self, x: torch.Tensor, step: int) -> Dict[str, float]:
+        """diffusion_model.py:473-492: sequential chunks of max_batch_size, each its own train_step."""
+        total_loss = 0.0
+        num_chunks = (x.shape[0] + self.max_batch_size - 1) // self.max_batch_size
+        for i in range(num_chunks):
+            chunk = x[i * self.max_batch_size:min((i + 1) * self.max_batch_size, x.shape[0])]
+            result = self.train_step(chunk, step * num_chunks + i)
+            total_loss += result['loss'] * chunk.shape[0]
+        return {'loss': total_loss / x.shape[0], 'lr': self.optimizer.param_groups[0]['lr'],
+                'gpu_memory': torch.cuda.memory_allocated() / 1024 ** 3 if torch.cuda.is_available() else 0}
 
     # ---- checkpoint ---------------------------------------------------------------------------
     def save_model(self, path: str):

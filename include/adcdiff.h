@@ -192,6 +192,43 @@ int adcdiff_ddim_sample_loop(adcdiff_unet* net, float* x, int ldx, int B, const 
                              long long noise_step_stride, uint64_t seed, uint64_t row_offset, void* workspace,
                              size_t workspace_bytes, adcdiff_stream_t stream);
 
+/* ------------------------------------------------------------------ training -------- */
+
+/* Gradient destinations, float32, same shapes as the parameters of adcdiff_unet_params.  Bias and GroupNorm
+ * gradients are ACCUMULATED with atomics and must be zero on entry; weight gradients are overwritten.
+ * condition_embed takes no gradient (the reference's train_step never passes a condition, diffusion_model.py:427,450). */
+typedef struct adcdiff_block_grads {
+    float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+    float *linear1_w, *linear1_b, *linear2_w, *linear2_b;
+    float *time_proj_w, *time_proj_b;
+    float *residual_w, *residual_b;
+} adcdiff_block_grads;
+typedef struct adcdiff_unet_grads {
+    float *time_lin1_w, *time_lin1_b, *time_lin2_w, *time_lin2_b;
+    adcdiff_block_grads blocks[10];
+    float *out_norm_w, *out_norm_b, *out_w, *out_b;
+} adcdiff_unet_grads;
+
+/* Workspace for one training forward + backward at this batch (activations stay in it between the two calls). */
+size_t adcdiff_unet_train_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int num_timesteps, int dtype, int batch);
+
+/* UNetModel.forward in training mode (diffusion_model.py:749-789 under model.train(), :413) with per-row timesteps:
+ * dropout(p) after the norm2 activation of every ResidualBlock (:898) from the counter RNG (dropout_seed, layer, row,
+ * column); leaves the activations the backward pass needs in the workspace.  Requires adcdiff_unet_pack after the last
+ * parameter change (the timestep tables are part of the differentiated graph). */
+int adcdiff_unet_train_forward(adcdiff_unet* net, const float* x, int ldx, int B, const int64_t* t_rows, float dropout_p,
+                               uint64_t dropout_seed, float* eps, int lde, void* workspace, size_t workspace_bytes,
+                               adcdiff_stream_t stream);
+
+/* F.mse_loss(target, pred) with mean reduction (diffusion_model.py:183): *loss_accum += scale * mean((target - pred)^2),
+ * dpred = d(scale * loss) / d(pred).  scale = 1 / gradient_accumulation_steps (:428, :451). */
+int adcdiff_mse_loss_grad(const float* pred, int ldp, const float* target, int ldt, float* dpred, int ldd, int B, int D, float scale,
+                          float* loss_accum, adcdiff_stream_t stream);
+
+/* loss.backward() through the denoiser (diffusion_model.py:431, :453): d_eps [B, output_dim] -> parameter gradients. */
+int adcdiff_unet_backward(adcdiff_unet* net, const float* d_eps, int lde, const adcdiff_unet_grads* grads, void* workspace,
+                          size_t workspace_bytes, adcdiff_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement ------ */
 
 /* Per-launch timing for benchmarks; no counterpart in the reference.  Between adcdiff_timing_begin and

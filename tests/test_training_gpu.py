@@ -1,0 +1,109 @@
+"""GPU parity of the training step (p_losses forward + backward, train_step) against numbers the reference produced
+(tests/golden/tiny.npz: loss, gradients of 14 tensors, global gradient norm, weights after one AdamW step).
+
+Tolerances: float32 path -- loss 1e-5 relative, gradients 2e-4 of the tensor's largest entry (the reference's own float32
+backward differs from a float64 evaluation by ~1e-5), weights after the step 2e-6 absolute (lr = 1e-4);
+bf16-operand path -- loss 2e-2, gradients 6e-2 of the largest entry.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import philox
+from oracle.weights import make_weights
+
+pytestmark = pytest.mark.gpu
+
+adcdiff = pytest.importorskip("adcdiff")
+SEED = 2025
+DIMS = (128, 128, 128)
+
+
+def build(dtype, **extra):
+    cfg = dict(input_dim=DIMS[0], hidden_dim=DIMS[1], output_dim=DIMS[2], num_timesteps=1000, beta_start=1e-4, beta_end=2e-2,
+               compute_dtype=dtype, **extra)
+    m = adcdiff.DiffusionModel(cfg)
+    w = make_weights(1234, *DIMS)
+    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
+    return m
+
+
+def cu(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda").to(dtype)
+
+
+def golden_tensor(g, key, got):
+    """Compare with a golden tensor stored whole or as a strided sample + norm."""
+    got = got.detach().float().cpu().numpy()
+    if key in g:
+        return got, g[key]
+    stride = int(g[key + ".stride"])
+    return got.ravel()[::stride], g[key + ".sample"]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_loss_and_gradients_match_reference(dtype, golden_tiny):
+    g = golden_tiny
+    m = build(dtype)
+    m.model.eval()   # the golden gradients were taken without dropout
+    nz = cu(philox.normal(SEED, philox.STREAM_QNOISE, 0, 0, 8, 128))
+    loss = m.p_losses(cu(g["train_x0"]), cu(g["train_t"], torch.int64), noise=nz)
+    assert abs(float(loss.detach()) - float(g["p_losses"])) < (1e-5 if dtype == "fp32" else 2e-2) * float(g["p_losses"])
+    loss.backward()
+    grads = {k: p.grad for k, p in m.model.named_parameters()}
+    tol = 2e-4 if dtype == "fp32" else 6e-2
+    def base(k):
+        for suffix in (".sample", ".stride", ".norm"):
+            if k.endswith(suffix) and (k[:-len(suffix)] + ".sample") in g.files:
+                return k[:-len(suffix)]
+        return k
+    names = sorted({base(k)[5:] for k in g.files if k.startswith("grad.")})
+    assert len(names) >= 14
+    for name in names:
+        got, ref = golden_tensor(g, "grad." + name, grads[name])
+        assert np.abs(got - ref).max() <= tol * max(np.abs(ref).max(), 1e-6), name
+    sq = sum(float((p.grad.double() ** 2).sum()) for p in m.model.parameters() if p.grad is not None)
+    assert abs(np.sqrt(sq) - float(g["grad_global_norm"])) < (1e-4 if dtype == "fp32" else 3e-2) * float(g["grad_global_norm"])
+    assert all(p.grad is None for p in m.model.condition_embed.parameters())
+
+
+def test_train_step_matches_reference(golden_tiny, monkeypatch):
+    g = golden_tiny
+    m = build("fp32", use_mixed_precision=False)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0   # as in the golden capture: train_step calls .train(), dropout off keeps it deterministic
+    nz = philox.normal(SEED, philox.STREAM_QNOISE, 0, 0, 8, 128)
+    # feed the recorded timesteps and noise through the two places train_step draws them
+    real_randint = torch.randint
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: cu(g["train_t"], torch.int64) if "device" in k else real_randint(*a, **k))
+    real_q = adcdiff.ops.q_sample
+    monkeypatch.setattr(adcdiff.ops, "q_sample", lambda *a, **k: real_q(*a, **{**k, "noise": cu(nz)}))
+    res = m.train_step(cu(g["train_x0"]), 0)
+    assert set(res) == {"loss", "lr", "gpu_memory", "gpu_memory_percent", "system_memory_percent"}
+    assert abs(res["loss"] - float(g["train_step_loss"])) < 1e-5 * float(g["train_step_loss"])
+    sd = m.model.state_dict()
+    w0 = make_weights(1234, *DIMS)
+    for name in ("output_layer.weight", "middle.0.linear1.weight", "encoder.0.norm1.weight", "time_embed.linear1.bias",
+                 "decoder.2.time_proj.1.weight"):
+        got, ref = golden_tensor(g, "train_step_after." + name, sd[name])
+        # AdamW's first step is lr * g / (|g| + 1e-8): entries whose gradient is within float32 noise of zero may move by a
+        # different fraction of lr = 1e-4, every other entry lands within 2e-6
+        diff = np.abs(got - ref)
+        assert (diff < 2e-6).mean() > 0.995 and diff.max() < 5e-5, (name, float(diff.max()), float((diff < 2e-6).mean()))
+        assert np.abs(got - (w0[name].ravel()[::int(g["train_step_after." + name + ".stride"])] if "train_step_after." + name not in g
+                             else w0[name])).max() > 5e-5, name   # the step really moved the weights (lr = 1e-4)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_training_reduces_loss_with_dropout_and_accumulation(dtype):
+    """Config-B-shaped run: loss falls over a few steps on a fixed batch with dropout active and chunking above max_batch_size."""
+    torch.manual_seed(0)
+    m = build(dtype, learning_rate=1e-3, max_batch_size=256, gradient_accumulation_steps=1)
+    x = cu(philox.normal(7, 52, 0, 0, 512, 128))
+    losses = [m.train_step(x, s)["loss"] for s in range(8)]
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0]
+    out = m.sample(4, use_ddim=False, seed=1, t_start=999, t_stop=990)   # the packed weights follow the optimiser
+    assert torch.isfinite(out).all()
