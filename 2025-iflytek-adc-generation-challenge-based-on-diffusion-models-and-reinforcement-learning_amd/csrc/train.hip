@@ -10,6 +10,8 @@
 // pre-norm tensor (gn_silu_bwd_kernel).  The time branch is differentiated through the per-timestep tables:
 // d(linear1 output) rows are scatter-added into d_tb_table[t_row], and the table-building GEMMs (M = T) are
 // back-propagated once per step.
+#include <cstdlib>
+
 #include "unet_plan.h"
 
 namespace adcdiff {
@@ -227,7 +229,7 @@ static size_t train_backward_bytes(adcdiff_unet* n, int B) {
     static const adcdiff_unet_grads none{};
     Bump ws(nullptr, 0);
     backward_impl(n, nullptr, 0, &none, B, ws, true, nullptr);
-    return ws.off + 256;
+    return ws.peak + 256;
 }
 
 extern "C" size_t adcdiff_unet_train_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int num_timesteps, int dtype, int batch) {
@@ -270,16 +272,33 @@ extern "C" int adcdiff_unet_backward(adcdiff_unet* n, const float* d_eps, int ld
     const size_t fwd = round_up(n->tape.ws_used, 256);
     if (workspace_bytes < fwd + train_backward_bytes(n, n->tape.B)) return fail(ADCDIFF_E_WORKSPACE, "unet_backward: workspace too small");
     Bump ws(reinterpret_cast<char*>(workspace) + fwd, workspace_bytes - fwd);
-    return backward_impl(n, d_eps, lde, gr, n->tape.B, ws, false, as_stream(stream_));
+    const int rc = backward_impl(n, d_eps, lde, gr, n->tape.B, ws, false, as_stream(stream_));
+    if (rc == ADCDIFF_OK && ws.peak > ws.cap) return fail(ADCDIFF_E_WORKSPACE, "unet_backward: internal sizing error (%zu > %zu)", ws.peak, ws.cap);
+    return rc;
 }
 
-#define RUN(expr) do { if (!dry) TRY(expr); } while (0)
+// ADCDIFF_DEBUG_SYNC=1 synchronises after every backward launch and names the first one that fails.
+static bool debug_sync() {
+    static const bool on = [] { const char* e = getenv("ADCDIFF_DEBUG_SYNC"); return e && e[0] == '1'; }();
+    return on;
+}
+#define RUN(expr)                                                                                              \
+    do {                                                                                                       \
+        if (!dry) {                                                                                            \
+            TRY(expr);                                                                                         \
+            if (debug_sync()) {                                                                                \
+                hipError_t e_ = hipStreamSynchronize(st);                                                      \
+                if (e_ != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "%s (block %d): %s", #expr, dbg_block, hipGetErrorString(e_)); \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
 
 static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adcdiff_unet_grads* gr, int B, Bump& ws, bool dry, hipStream_t st) {
     const Tape& tp = n->tape;
     const int Bp = (int)round_up((size_t)B, 128), dt = n->dtype, H = n->H, O = n->O, Tp = n->Tp, SN = n->sumN;
     const size_t e = (size_t)n->esz;
     const adcdiff_unet_params& p = n->prm;
+    int dbg_block = 10;
 
     // gradients of the block outputs, and of the per-timestep table
     float* dO[10];
@@ -307,6 +326,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
     const size_t mark = ws.off;
     for (int i = 9; i >= 0; --i) {
         ws.off = mark;   // per-block temporaries are reused
+        dbg_block = i;
         const BlockPlan& b = n->blk[i];
         const BlockTape& bt = tp.blk[i];
         const adcdiff_block_params& q = p.blocks[i];

@@ -28,11 +28,12 @@ static inline int num_groups(int dim) {   // diffusion_model.py:723-730, 840-847
 
 struct Bump {
     char* base;
-    size_t off = 0, cap;
+    size_t off = 0, cap, peak = 0;   // peak: high-water mark (callers may rewind `off` to reuse temporaries)
     Bump(void* b, size_t c) : base(reinterpret_cast<char*>(b)), cap(c) {}
     void* take(size_t bytes) {
-        void* p = base + off;   // in a dry run base is null and only `off` matters
+        void* p = base + off;   // in a dry run base is null and only the offsets matter
         off += round_up(bytes, 256);
+        if (off > peak) peak = off;
         return p;
     }
 };

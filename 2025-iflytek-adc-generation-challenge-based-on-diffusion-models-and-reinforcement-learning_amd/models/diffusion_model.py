@@ -669,6 +669,10 @@ class DiffusionModel(nn.Module):
         loss = loss / self.gradient_accumulation_steps
         loss.backward()
         if (step + 1) % self.gradient_accumulation_steps == 0:
+            # data parallel (one process per GPU): average the gradients over the ranks before clipping, so that the
+            # clipped norm and the AdamW step are identical on every rank; a no-op in a single process
+            from ..parallel import allreduce_gradients
+            allreduce_gradients(self.model.parameters())
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=1.0)
             self.optimizer.step()
             self.optimizer.zero_grad()

@@ -68,3 +68,36 @@ def sample_ddpm_sharded(model, total: int, condition: Optional[torch.Tensor] = N
             cond = cond.expand(count, -1) if cond.shape[0] == 1 else cond[first:first + count]
         return model.sample(count, condition=cond, use_ddim=use_ddim, ddim_steps=ddim_steps, eta=eta, seed=seed, row_offset=first)
     return sample_sharded(run, total, group)
+
+
+def allreduce_gradients(parameters, group=None, bucket_bytes: int = 256 << 20) -> None:
+    """Data-parallel gradient averaging: sum the ranks' `.grad` tensors and divide by the world size.
+
+    Gradients are packed into flat float32 buckets (default 256 MiB: the whole 44.3 M-parameter denoiser is 177 MB, i.e.
+    one all-reduce; xGMI is point-to-point, so few large ring collectives beat many small ones) and reduced with one
+    collective per bucket.  Every rank must hold gradients for the same parameters.  No-op without a process group."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    world = dist.get_world_size(group)
+    params = [p for p in parameters if p.grad is not None]
+    bucket, size = [], 0
+    buckets = []
+    for p in params:
+        nbytes = p.grad.numel() * p.grad.element_size()
+        if bucket and size + nbytes > bucket_bytes:
+            buckets.append(bucket)
+            bucket, size = [], 0
+        bucket.append(p)
+        size += nbytes
+    if bucket:
+        buckets.append(bucket)
+    for bucket in buckets:
+        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
+        off = 0
+        for p in bucket:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n

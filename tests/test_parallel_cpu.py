@@ -90,3 +90,27 @@ def test_generator_driver_contract():
     assert calls[1][1] is None
     with pytest.raises(ValueError):
         adcdiff.MoleculeGenerator({}).generate_initial_features(1)
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 1000, 37, 4096)] + [torch.nn.Parameter(torch.zeros(3))]
+        for i, p in enumerate(params[:-1]):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        parallel.allreduce_gradients(params, bucket_bytes=4200)      # several buckets; the last parameter has no gradient
+        np.save(os.path.join(out_dir, "g%d.npy" % rank), np.concatenate([p.grad.numpy().ravel() for p in params[:-1]]))
+        assert params[-1].grad is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_averages_over_ranks(tmp_path):
+    world = 2
+    mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    expect = np.concatenate([np.full(n, 1.5 * (i + 1), dtype=np.float32) for i, n in enumerate((5, 1000, 37, 4096))])
+    for rank in range(world):
+        assert np.array_equal(np.load(str(tmp_path / ("g%d.npy" % rank))), expect)

@@ -69,6 +69,7 @@ def test_tiny_forward_blocks_and_steps(dtype, golden_tiny):
         h1 = m.model.encoder[1](cu(g["fwd_uncond_block.encoder.0"]), t_emb).cpu().numpy()
         assert rel_err(h1, g["fwd_uncond_block.encoder.1"]) < FWD_TOL[dtype]
     nzl = cu(philox.normal(SEED, philox.STREAM_QNOISE, 0, 0, 8, 128))
+    m.model.eval()   # the recorded loss was taken without dropout
     loss = m.p_losses(cu(g["train_x0"]), cu(g["train_t"], torch.int64), noise=nzl)
     assert abs(float(loss) - float(g["p_losses"])) < (1e-4 if dtype == "fp32" else 2e-2) * float(g["p_losses"])
 

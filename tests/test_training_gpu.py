@@ -107,3 +107,39 @@ def test_training_reduces_loss_with_dropout_and_accumulation(dtype):
     assert losses[-1] < losses[0]
     out = m.sample(4, use_ddim=False, seed=1, t_start=999, t_stop=990)   # the packed weights follow the optimiser
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_large_batch_gradient_is_mean_of_half_batch_gradients(dtype):
+    """emb 512 / hidden 256 at batch 4096 (the per-GPU training shape): the loss is a mean over rows, so the gradient of
+    the whole batch equals the mean of the gradients of its two halves on the same timesteps and noise.  Exercises the
+    training workspace at full size.  Tolerance: float32 summation order only (1e-4 of the largest entry); bf16 operands
+    round identically row by row, so the same bound holds with 2e-3 for the bf16-rounded dW accumulations."""
+    dims = (512, 256, 512)
+    cfg = dict(input_dim=dims[0], hidden_dim=dims[1], output_dim=dims[2], compute_dtype=dtype, max_batch_size=4096)
+    m = adcdiff.DiffusionModel(cfg)
+    w = make_weights(1234, *dims)
+    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
+    m.model.eval()
+    B = 4096
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(B, dims[0], generator=gen).cuda()
+    nz = torch.randn(B, dims[0], generator=gen).cuda()
+    t = torch.randint(0, 1000, (B,), generator=gen).cuda()
+
+    def grads(lo, hi):
+        m.model.zero_grad(set_to_none=True)
+        loss = m.p_losses(x[lo:hi], t[lo:hi], noise=nz[lo:hi])
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in m.model.named_parameters() if p.grad is not None}
+
+    l_all, g_all = grads(0, B)
+    l_a, g_a = grads(0, B // 2)
+    l_b, g_b = grads(B // 2, B)
+    assert abs(l_all - 0.5 * (l_a + l_b)) < 1e-5 * l_all
+    tol = 1e-4 if dtype == "fp32" else 2e-3
+    assert len(g_all) >= 100
+    for k, ga in g_all.items():
+        ref = 0.5 * (g_a[k] + g_b[k])
+        assert torch.isfinite(ga).all(), k
+        assert float((ga - ref).abs().max()) <= tol * max(float(ref.abs().max()), 1e-6), k
