@@ -15,6 +15,12 @@
 // a lane owns 8 contiguous columns of a row; GroupNorm statistics are in-lane / DPP sums.  The consumer's
 // GroupNorm is applied by the producer, so no layer output is ever re-read just to be normalised.
 #include <cstdlib>
+#ifdef ADCDIFF_STAMPS
+#include <algorithm>
+#include <cstdio>
+#include <map>
+#include <vector>
+#endif
 #include <type_traits>
 
 #include "common.h"
@@ -50,6 +56,9 @@ struct GemmParams {
     int n_gn;
     GnOut gn[2];
     float eps;
+#ifdef ADCDIFF_STAMPS
+    long long* stamps;
+#endif
 };
 
 // LDS-DMA copy of 16 bytes per lane: the wave's 64 lanes fill 1 KiB starting at the wave-uniform `lds`.
@@ -62,6 +71,13 @@ template <typename T>
 __device__ __forceinline__ float silu_out(float v) {
     if constexpr (sizeof(T) == 2) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));   // result is rounded to bf16
     else return silu_f(v);
+}
+
+// 1 / sqrt(x): the hardware estimate (1 ulp) where the result is rounded to bf16 anyway, the exact pair otherwise.
+template <typename T>
+__device__ __forceinline__ float inv_sqrt_out(float x) {
+    if constexpr (sizeof(T) == 2) return __builtin_amdgcn_rsqf(x);
+    else return 1.0f / __builtin_sqrtf(x);
 }
 
 template <typename T>
@@ -158,7 +174,7 @@ struct Epilogue {
                 float q = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { const float d = v[4 * h + k] - mean; q += d * d; }
-                const float rstd = 1.0f / __builtin_sqrtf(q * 0.25f + eps);
+                const float rstd = inv_sqrt_out<T>(q * 0.25f + eps);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) y[4 * h + k] = silu_out<T>((v[4 * h + k] - mean) * rstd * gam[4 * h + k] + bet[4 * h + k]);
             }
@@ -181,7 +197,7 @@ struct Epilogue {
                 q = q + oq + delta * delta * (0.5f * IN_WAVE);
                 mean = 0.5f * (mean + om);
             }
-            const float rstd = 1.0f / __builtin_sqrtf(q * (1.0f / GS) + eps);
+            const float rstd = inv_sqrt_out<T>(q * (1.0f / GS) + eps);
 #pragma unroll
             for (int k = 0; k < 8; ++k) y[k] = silu_out<T>((v[k] - mean) * rstd * gam[k] + bet[k]);
         }
@@ -202,7 +218,95 @@ struct Epilogue {
         }
     }
 
+    // Accumulators of row chunk H (32 rows of the wave tile) -> this wave's staging region.
+    template <int H>
+    static __device__ __forceinline__ void stage_chunk(const acc_t (&acc)[TM][TN], float* stage, int crow0, int ccol) {
+        if constexpr (H < NCHUNK) {
+#pragma unroll
+            for (int i = H * (CH / TS); i < (H + 1) * (CH / TS); ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < NACC; ++r) {
+                        const int crow = i * TS + crow0 + (BF ? r : (r & 3) + 8 * (r >> 2)) - H * CH;
+                        stage[crow * LDW + j * TS + ccol] = acc[i][j][r];
+                    }
+        }
+    }
+
+    // One step: RPS rows of the staged chunk, a lane owning 8 contiguous columns of one row.
+    template <bool PRM_IN_REGS>
+    static __device__ __forceinline__ void step(const GemmParams& p, const float* stage, const float* prm, float* xch_base, int h, int st,
+                                                int step_id, int m0, int wm, int wave, int rr, int cg, int bcol, long col,
+                                                const float (&cb)[8], const float (&g0)[8], const float (&b0)[8],
+                                                const float (&g1)[8], const float (&b1)[8]) {
+        const T* const resp = reinterpret_cast<const T*>(p.residual);
+        const bool row_rb = p.rowbias != nullptr && (p.rowbias_idx != nullptr || p.ldrb != 0);
+        const int crow = st * RPS + rr;
+        const long row = m0 + wm * WTM + h * CH + crow;
+        const bool live = row < p.m_valid;
+        const long lrow = live ? row : 0;    // dead rows read row 0's side inputs (always valid) and store nothing
+        float v[8];
+        load8(stage + crow * LDW + cg * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += cb[k];
+        if (row_rb) {
+            const long ridx = p.rowbias_idx ? (long)p.rowbias_idx[lrow] : lrow;
+            float t[8];
+            load8(p.rowbias + ridx * p.ldrb + col, t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += t[k];
+        }
+        if (resp) {
+            const T* rp = resp + lrow * p.ldr + col;
+            if constexpr (BF) {
+                const bf16x8 t = *reinterpret_cast<const bf16x8*>(rp);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+            } else {
+                float t[8];
+                load8(reinterpret_cast<const float*>(rp), t);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += t[k];
+            }
+        }
+        if (p.act == 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = silu_f(v[k]);
+        }
+        if (p.out_f32 && live) store8<float>(p.out_f32 + row * p.ldo_f32 + col, v);
+        if (p.out_op && live) store8<T>(reinterpret_cast<T*>(p.out_op) + row * p.ldo_op + col, v);
+        float* const xch = xch_base + (step_id & 1) * (2 * XB);
+        if (p.n_gn > 0) {
+            T* const dst = reinterpret_cast<T*>(p.gn[0].out) + row * p.gn[0].ldo + col;
+            if constexpr (PRM_IN_REGS) {
+                gn_dispatch(p.gn[0].gs, v, g0, b0, dst, p.eps, live, xch, wave, rr, cg);
+            } else {
+                float gam[8], bet[8];   // from LDS at each use: sixteen registers less per output across the rolled loop
+                load8(prm + BN + bcol, gam);
+                load8(prm + 2 * BN + bcol, bet);
+                gn_dispatch(p.gn[0].gs, v, gam, bet, dst, p.eps, live, xch, wave, rr, cg);
+            }
+        }
+        if (p.n_gn > 1) {
+            T* const dst = reinterpret_cast<T*>(p.gn[1].out) + row * p.gn[1].ldo + col;
+            if constexpr (PRM_IN_REGS) {
+                gn_dispatch(p.gn[1].gs, v, g1, b1, dst, p.eps, live, xch + XB, wave, rr, cg);
+            } else {
+                float gam[8], bet[8];
+                load8(prm + 3 * BN + bcol, gam);
+                load8(prm + 4 * BN + bcol, bet);
+                gn_dispatch(p.gn[1].gs, v, gam, bet, dst, p.eps, live, xch + XB, wave, rr, cg);
+            }
+        }
+    }
+
     // smem_epi: NWAVE private staging regions (reusing the main loop's LDS); prm / xch: behind the main loop's LDS.
+    // ROLLED: the chunk and step loops stay loops, so the step body exists once per GroupNorm variant and is re-executed
+    // from the instruction cache -- for the one-workgroup-per-CU kernel, whose waves otherwise all fetch ~100 KB of
+    // straight-line code cold.  Only the accumulator -> LDS copy needs compile-time register indices, hence the switch.
+    // Unrolled (the kernels with 3-4 workgroups per CU): steps overlap each other's loads, parameters sit in registers.
+    template <bool ROLLED>
     static __device__ __forceinline__ void run(const acc_t (&acc)[TM][TN], const GemmParams& p, int m0, int n0, int wm, int wn, int wave,
                                                int lane, float* smem_epi, float* prm, float* xch_base) {
         float* const stage = smem_epi + wave * (CH * LDW);
@@ -213,68 +317,36 @@ struct Epilogue {
         const long col = n0 + bcol;
         float cb[8], g0[8], b0[8], g1[8], b1[8];
         load8(prm + bcol, cb);
-        load8(prm + BN + bcol, g0);
-        load8(prm + 2 * BN + bcol, b0);
-        load8(prm + 3 * BN + bcol, g1);
-        load8(prm + 4 * BN + bcol, b1);
-        const T* const resp = reinterpret_cast<const T*>(p.residual);
-        const bool row_rb = p.rowbias != nullptr && (p.rowbias_idx != nullptr || p.ldrb != 0);
-        int step_id = 0;
-#pragma unroll
-        for (int h = 0; h < NCHUNK; ++h) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (i / (CH / TS) != h) continue;   // compile-time after unrolling
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < NACC; ++r) {
-                        const int crow = i * TS + crow0 + (BF ? r : (r & 3) + 8 * (r >> 2)) - h * CH;
-                        stage[crow * LDW + j * TS + ccol] = acc[i][j][r];
-                    }
+        if constexpr (!ROLLED) {
+            load8(prm + BN + bcol, g0);
+            load8(prm + 2 * BN + bcol, b0);
+            load8(prm + 3 * BN + bcol, g1);
+            load8(prm + 4 * BN + bcol, b1);
+        }
+        if constexpr (ROLLED) {
+            int step_id = 0;
+#pragma unroll 1
+            for (int h = 0; h < NCHUNK; ++h) {
+                switch (h) {
+                    case 0: stage_chunk<0>(acc, stage, crow0, ccol); break;
+                    case 1: stage_chunk<1>(acc, stage, crow0, ccol); break;
+                    case 2: stage_chunk<2>(acc, stage, crow0, ccol); break;
+                    default: stage_chunk<3>(acc, stage, crow0, ccol); break;
+                }
+#pragma unroll 1
+                for (int st = 0; st < NSTEP; ++st, ++step_id)
+                    step<false>(p, stage, prm, xch_base, h, st, step_id, m0, wm, wave, rr, cg, bcol, col, cb, g0, b0, g1, b1);
             }
+        } else {
 #pragma unroll
-            for (int st = 0; st < NSTEP; ++st, ++step_id) {
-                const int crow = st * RPS + rr;
-                const long row = m0 + wm * WTM + h * CH + crow;
-                const bool live = row < p.m_valid;
-                const long lrow = live ? row : 0;    // dead rows read row 0's side inputs (always valid) and store nothing
-                float v[8];
-                load8(stage + crow * LDW + cg * 8, v);
+            for (int h = 0; h < NCHUNK; ++h) {
+                if (h == 0) stage_chunk<0>(acc, stage, crow0, ccol);
+                if (h == 1) stage_chunk<1>(acc, stage, crow0, ccol);
+                if (h == 2) stage_chunk<2>(acc, stage, crow0, ccol);
+                if (h == 3) stage_chunk<3>(acc, stage, crow0, ccol);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += cb[k];
-                if (row_rb) {
-                    const long ridx = p.rowbias_idx ? (long)p.rowbias_idx[lrow] : lrow;
-                    float t[8];
-                    load8(p.rowbias + ridx * p.ldrb + col, t);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += t[k];
-                }
-                if (resp) {
-                    const T* rp = resp + lrow * p.ldr + col;
-                    if constexpr (BF) {
-                        const bf16x8 t = *reinterpret_cast<const bf16x8*>(rp);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
-                    } else {
-                        float t[8];
-                        load8(reinterpret_cast<const float*>(rp), t);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] += t[k];
-                    }
-                }
-                if (p.act == 1) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = silu_f(v[k]);
-                }
-                if (p.out_f32 && live) store8<float>(p.out_f32 + row * p.ldo_f32 + col, v);
-                if (p.out_op && live) store8<T>(reinterpret_cast<T*>(p.out_op) + row * p.ldo_op + col, v);
-                float* const xch = xch_base + (step_id & 1) * (2 * XB);
-                if (p.n_gn > 0)
-                    gn_dispatch(p.gn[0].gs, v, g0, b0, reinterpret_cast<T*>(p.gn[0].out) + row * p.gn[0].ldo + col, p.eps, live, xch, wave, rr, cg);
-                if (p.n_gn > 1)
-                    gn_dispatch(p.gn[1].gs, v, g1, b1, reinterpret_cast<T*>(p.gn[1].out) + row * p.gn[1].ldo + col, p.eps, live, xch + XB,
-                                wave, rr, cg);
+                for (int st = 0; st < NSTEP; ++st)
+                    step<true>(p, stage, prm, xch_base, h, st, h * NSTEP + st, m0, wm, wave, rr, cg, bcol, col, cb, g0, b0, g1, b1);
             }
         }
     }
@@ -409,7 +481,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
         __syncthreads();
     }
 
-    Epi::run(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
+    Epi::template run<false>(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
 }
 
 // ---- 256 x 256 tile, 8 waves (2 x 4, 128 x 64 per wave), bf16 ------------------------------------------------
@@ -442,6 +514,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmParams p
 
     int bid = blockIdx.x;
     const int nwg = gridDim.x;
+#ifdef ADCDIFF_STAMPS
+    const long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
     Epi::stage_params(p, n0, tid, prm);
@@ -501,6 +576,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+#ifdef ADCDIFF_STAMPS
+    const long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = 0; t < nt; ++t) {
         const char* sa = smem + (t & 1) * STAGE_BYTES;
         const char* sb = sa + 32768;
@@ -533,7 +611,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmParams p
     }
 #undef ADCDIFF_ISSUE_NEXT
     __syncthreads();
-    Epi::run(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
+#ifdef ADCDIFF_STAMPS
+    const long long st2 = __builtin_amdgcn_s_memtime();
+#endif
+    Epi::template run<true>(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
+#ifdef ADCDIFF_STAMPS
+    const long long st3 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long st4 = __builtin_amdgcn_s_memtime(), rt4 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && blockIdx.x < 8192) {
+        long long* o = p.stamps + ((long)blockIdx.x * 8 + wave) * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = rt0; o[6] = rt4;
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); o[7] = hw;
+    }
+#endif
 }
 
 static int launch256(const GemmParams& p, hipStream_t stream) {
@@ -546,8 +637,49 @@ static int launch256(const GemmParams& p, hipStream_t stream) {
     }
     GemmParams q = p;
     q.ntn = p.N / 256;
+#ifdef ADCDIFF_STAMPS
+    static long long* dbuf = nullptr;
+    if (!dbuf) (void)hipMalloc(&dbuf, (size_t)8192 * 64 * 8);
+    q.stamps = dbuf;
+#endif
     const int grid = (p.M / 256) * q.ntn;
     hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(grid), dim3(512), smem, stream, q);
+#ifdef ADCDIFF_STAMPS
+    {
+        static int calls = 0;
+        if (++calls == 10 && grid <= 8192) {
+            (void)hipDeviceSynchronize();
+            std::vector<long long> h((size_t)grid * 64);
+            (void)hipMemcpy(h.data(), q.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+            double pro = 0, mainl = 0, epi = 0, drain = 0; long long rmin = 1LL << 62, rmax = 0;
+            double pw[8] = {0}, ew[8] = {0};
+            for (int b = 0; b < grid; ++b)
+                for (int w = 0; w < 8; ++w) {
+                    const long long* o = &h[((size_t)b * 8 + w) * 8];
+                    pro += o[1] - o[0]; mainl += o[2] - o[1]; epi += o[3] - o[2]; drain += o[4] - o[3];
+                    pw[w] += o[1] - o[0]; ew[w] += o[3] - o[2];
+                    if (o[5] < rmin) rmin = o[5];
+                    if (o[6] > rmax) rmax = o[6];
+                }
+            const double n = (double)grid * 8;
+            fprintf(stderr, "[stamps] grid %d: prologue %.0f  main %.0f  epilogue %.0f  drain %.0f cycles (mean per wave); kernel span %.1f us\n",
+                    grid, pro / n, mainl / n, epi / n, drain / n, (rmax - rmin) / 100.0);
+            // per-CU busy accounting: sum of block lifetimes per CU (realtime, 100 MHz) vs the span
+            std::map<unsigned, std::vector<std::pair<long long, long long>>> cu;
+            for (int b = 0; b < grid; ++b) {
+                const long long* o = &h[((size_t)b * 8) * 8];
+                cu[(unsigned)o[7] & 0xFFFFFF00u].push_back({o[5], o[6]});
+            }
+            double gap = 0, life = 0; size_t nb = 0;
+            for (auto& kv : cu) {
+                auto& v = kv.second; std::sort(v.begin(), v.end());
+                for (size_t i = 0; i < v.size(); ++i) { life += v[i].second - v[i].first; ++nb; if (i) gap += v[i].first - v[i - 1].second; }
+            }
+            fprintf(stderr, "[stamps] %zu CU ids, mean block lifetime %.2f us, mean gap between successive blocks on a CU %.2f us\n", cu.size(),
+                    life / nb / 100.0, gap / (nb - cu.size()) / 100.0);
+        }
+    }
+#endif
     return check_launch("gemm256");
 }
 
