@@ -65,7 +65,7 @@ class TimingRecord(C.Structure):
                 ("bytes", C.c_double)]
 
 
-KIND_GEMM_F32, KIND_GEMM_BF16, KIND_GROUPNORM, KIND_UPDATE = 0, 1, 2, 3
+KIND_GEMM_F32, KIND_GEMM_BF16, KIND_GROUPNORM, KIND_UPDATE, KIND_GEMM_BF16_T256 = 0, 1, 2, 3, 4
 
 # name -> (restype, argtypes): every symbol include/adcdiff.h declares
 SIGNATURES = {

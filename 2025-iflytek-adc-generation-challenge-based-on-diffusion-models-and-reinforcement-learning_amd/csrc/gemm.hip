@@ -758,23 +758,26 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     p.out_op = a.out_op; p.ldo_op = a.ldo_op;
     const double esz = esize;
     const double nout = (a.out_f32 ? 4.0 : 0.0) + esz * ((a.out_op ? 1 : 0) + a.n_gn);
-    TimingScope ts(a.dtype == ADCDIFF_BF16 ? ADCDIFF_KIND_GEMM_BF16 : ADCDIFF_KIND_GEMM_F32, a.M, a.N, ktot, 2.0 * a.M * a.N * ktot,
-                   esz * ((double)a.M * ktot + (double)a.N * ktot) + (double)a.M * a.N * (nout + (a.residual ? esz : 0.0)), stream);
-    // Kernel choice for bf16, from A/B timings of both kernels on the denoiser's layer shapes at M = 65536: the
-    // 256 x 256 kernel (one workgroup per CU, prefetch under the MFMAs) wins once the K loop is long enough to
-    // amortise its exposed prologue / epilogue; the 128-row kernel (3-4 workgroups per CU) wins elsewhere.
+    // Kernel choice for bf16, from A/B timings of the kernels on the denoiser's layer shapes at M = 65536: the
+    // 256 x 256 kernel (one workgroup per CU, prefetch under the MFMAs, rolled epilogue) wins once the K loop is long
+    // enough to amortise its exposed prologue / epilogue, and where the epilogue is the larger part (three outputs from
+    // K >= 768); the 128-row kernel (3-4 workgroups per CU) wins elsewhere.
+    bool big = false;
     if (a.dtype == ADCDIFF_BF16 && a.M % 256 == 0 && a.N % 256 == 0 && a.tile_hint != 128) {
         static const int forced = [] { const char* e = getenv("ADCDIFF_GEMM_TILE"); return e ? atoi(e) : 0; }();   // measurement aid
-        if (forced == 256) return launch256(p, stream);
         const bool enough_tiles = forced != 128 && (long)(a.M / 256) * (a.N / 256) >= 192;
-        const bool long_k = ktot >= 2048;
-        if (a.tile_hint == 256 || (enough_tiles && long_k)) return launch256(p, stream);
+        const bool long_k = ktot >= 2048 || (nout >= 3.0 * esz && ktot >= 768);
+        big = forced == 256 || a.tile_hint == 256 || (enough_tiles && long_k);
     }
     // few rows (the float32 batch-4096 case, small generation batches): 64 x 64 tiles give four times the workgroups
     bool small = (long)(a.M / 128) * (a.N / (wide ? 128 : 64)) < 256 && a.tile_hint != 128;
     // only where the GroupNorm groups stay inside a 32-column wave tile: every kernel then sums a group in the same
     // order, so a row's result does not depend on the batch size it is computed in (bit for bit)
     for (int g = 0; g < a.n_gn; ++g) small = small && a.gn[g].group_size <= 32;
+    const int kind = a.dtype == ADCDIFF_F32 ? ADCDIFF_KIND_GEMM_F32 : big ? ADCDIFF_KIND_GEMM_BF16_T256 : ADCDIFF_KIND_GEMM_BF16;
+    TimingScope ts(kind, a.M, a.N, ktot, 2.0 * a.M * a.N * ktot,
+                   esz * ((double)a.M * ktot + (double)a.N * ktot) + (double)a.M * a.N * (nout + (a.residual ? esz : 0.0)), stream);
+    if (big) return launch256(p, stream);
     if (a.dtype == ADCDIFF_BF16) {
         if (small) return launch<bf16_t, 64, 64>(p, stream);
         return wide ? launch<bf16_t, 128, 128>(p, stream) : launch<bf16_t, 128, 64>(p, stream);

@@ -52,14 +52,17 @@ def build_model(dtype, weights):
     return model
 
 
-def measured_traffic(kernel_key):
-    """HBM bytes per launch of a kernel from the newest committed counter summary (profiles/*_traffic.json, produced by
-    profiles/collect.sh + summarize.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same benchmark)."""
+def measured_traffic(kernel_key, dtype, batch):
+    """HBM bytes per launch of a kernel from the newest committed counter summary of this same workload (profiles/*_traffic.json,
+    produced by profiles/collect.sh + summarize.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this benchmark)."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
             d = json.load(open(f))
+            line = d.get("bench_line_under_profiler", {})
+            if line.get("dtype") != dtype or line.get("config", {}).get("per_gpu_batch") != batch:
+                continue
             v = d["kernels"].get(kernel_key, {}).get("hbm_bytes_per_launch")
             if v:
                 best = (v, os.path.basename(f))
@@ -69,39 +72,55 @@ def measured_traffic(kernel_key):
 
 
 def roofline(model, dtype, batch, window=8):
-    """Live per-launch hipEvent timing of `window` denoising steps: achieved rate of the GEMM kernel
-    (algorithmic FLOPs / its device time) and of the schedule-update kernel (algorithmic bytes / time)."""
+    """Live per-launch hipEvent timing (on the stream the kernels run on) of `window` denoising steps.
+
+    `dominant`: the kernel with the largest share of the step -- the 256 x 256-tile bf16 GEMM (bf16 workload) or the
+    float32 GEMM -- achieved = FLOPs of its launches (2 M N K each, the layer as executed) / their device time.
+    `gemms`: every GEMM launch of the step against the algorithmic 81.92 MFLOP per sample and step.
+    Schedule-update and GroupNorm kernels: algorithmic bytes / device time."""
     with ops.timing(64 * window + 64) as tm:
         model.p_sample_loop((batch, DIMS[2]), seed=SEED, t_start=999, t_stop=1000 - window)
         torch.cuda.synchronize()
-    kind = _lib.KIND_GEMM_BF16 if dtype == "bf16" else _lib.KIND_GEMM_F32
-    gemm = [r for r in tm.records if r["kind"] == kind]
+    gemm_kinds = (_lib.KIND_GEMM_BF16, _lib.KIND_GEMM_BF16_T256) if dtype == "bf16" else (_lib.KIND_GEMM_F32,)
+    gemm = [r for r in tm.records if r["kind"] in gemm_kinds]
+    big = [r for r in gemm if r["kind"] == _lib.KIND_GEMM_BF16_T256]
+    dom, dom_name, dom_key = (big, "gemm256_bf16_kernel", "gemm256_kernel<bf16>") if big else \
+        (gemm, "gemm_nt_kernel<%s>" % ("bf16" if dtype == "bf16" else "float"), "gemm_nt_kernel<%s>" % ("bf16" if dtype == "bf16" else "float"))
     upd = [r for r in tm.records if r["kind"] == _lib.KIND_UPDATE]
     gn = [r for r in tm.records if r["kind"] == _lib.KIND_GROUPNORM]
-    gemm_ms = sum(r["ms"] for r in gemm)
-    algo = ALGO_FLOP_PER_SAMPLE_STEP * batch * window
-    achieved = algo / (gemm_ms * 1e-3) / 1e12
-    main = {"bound": "mfma", "kernel": "gemm_nt_kernel<%s,128,128>" % ("bf16" if dtype == "bf16" else "float"),
-            "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_TFLOPS[dtype], 4), "traffic": None,
-            "algorithmic_bytes_per_launch": sum(r["bytes"] for r in gemm) / max(1, len(gemm)),
-            "launches": len(gemm), "avg_launch_ms": round(gemm_ms / max(1, len(gemm)), 4),
-            "flop_per_launch": algo / max(1, len(gemm)), "gemm_ms_per_denoise_step": round(gemm_ms / window, 4)}
-    tr = measured_traffic("gemm_nt_kernel<bf16>" if dtype == "bf16" else "gemm_nt_kernel<float>") if batch == 65536 else None
+    peak = PEAK_TFLOPS[dtype]
+
+    dom_ms = sum(r["ms"] for r in dom)
+    dom_fl = sum(r["flops"] for r in dom)
+    achieved = dom_fl / (dom_ms * 1e-3) / 1e12
+    main = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None, "launches": len(dom), "avg_launch_ms": round(dom_ms / max(1, len(dom)), 4),
+            "flop_per_launch": dom_fl / max(1, len(dom)), "algorithmic_bytes_per_launch": sum(r["bytes"] for r in dom) / max(1, len(dom)),
+            "share_of_gemm_time": round(dom_ms / max(1e-9, sum(r["ms"] for r in gemm)), 3)}
+    tr = measured_traffic(dom_key, dtype, batch)
     if tr:
         main["traffic"], main["traffic_source"] = tr[0], "profiles/" + tr[1]
+    gemm_ms = sum(r["ms"] for r in gemm)
+    algo = ALGO_FLOP_PER_SAMPLE_STEP * batch * window
+    allg = {"bound": "mfma", "kernel": "all denoiser GEMM launches of a step", "achieved": round(algo / (gemm_ms * 1e-3) / 1e12, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(algo / (gemm_ms * 1e-3) / 1e12 / peak, 4), "launches_per_step": len(gemm) // window,
+            "algorithmic_flop_per_sample_step": ALGO_FLOP_PER_SAMPLE_STEP, "executed_flop_per_sample_step": sum(r["flops"] for r in gemm) / window / batch,
+            "gemm_ms_per_denoise_step": round(gemm_ms / window, 4)}
     upd_ms = sum(r["ms"] for r in upd)
     upd_bytes = sum(r["bytes"] for r in upd)
     update = {"bound": "hbm", "kernel": "ddpm_step_kernel<false>", "achieved": round(upd_bytes / (upd_ms * 1e-3) / 1e9, 1),
               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(upd_bytes / (upd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
               "traffic": None, "launches": len(upd), "avg_launch_ms": round(upd_ms / max(1, len(upd)), 4),
               "bytes_per_launch": upd_bytes / max(1, len(upd))}
+    tr = measured_traffic("ddpm_step_kernel", dtype, batch)
+    if tr:
+        update["traffic"], update["traffic_source"] = tr[0], "profiles/" + tr[1]
     gn_ms = sum(r["ms"] for r in gn)
     gn_bytes = sum(r["bytes"] for r in gn)
     norm = {"bound": "hbm", "kernel": "gn_silu_vec_kernel", "achieved": round(gn_bytes / (gn_ms * 1e-3) / 1e9, 1),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gn_bytes / (gn_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "launches": len(gn), "ms_per_denoise_step": round(gn_ms / window, 4)}
-    return main, update, norm
+    return main, allg, update, norm
 
 
 def cpu_baseline(weights, target_seconds=15.0):
@@ -190,7 +209,7 @@ def main():
     finite = bool(torch.isfinite(out).all().item())
 
     if rank == 0:
-        main_roof, upd_roof, gn_roof = roofline(model, dtype, batch)
+        main_roof, all_roof, upd_roof, gn_roof = roofline(model, dtype, batch)
         samples = world * batch * args.steps * (T / 1000.0)
         line = {
             "metric": "DDPM samples/sec (T=1000)", "value": round(samples / elapsed, 2), "unit": "samples/s",
@@ -200,7 +219,7 @@ def main():
                        "global_batch": world * batch, "timesteps": T, "sampler": "p_sample_loop (DDPM, linear beta 1e-4..2e-2)",
                        "parallelism": "rows sharded over %d GPU(s), RCCL all-gather of latents" % world,
                        "weights": "random (counter hash, xavier range), no checkpoint ships"},
-            "roofline": main_roof, "roofline_schedule_update": upd_roof, "groupnorm_kernel": gn_roof,
+            "roofline": main_roof, "roofline_all_gemms": all_roof, "roofline_schedule_update": upd_roof, "groupnorm_kernel": gn_roof,
             "ms_per_denoise_step": round(elapsed / args.steps / T * 1e3, 4), "outputs_finite": finite,
         }
         if world == 1 and not args.no_cpu_baseline:

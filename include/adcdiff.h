@@ -236,7 +236,8 @@ int adcdiff_unet_backward(adcdiff_unet* net, const float* d_eps, int lde, const 
  * bracketed by a pair of hipEvents on the stream it is launched on (up to max_records launches; later
  * ones are not recorded).  adcdiff_timing_end synchronises those events and returns one record per
  * launch.  Not thread safe; not for use under graph capture. */
-enum { ADCDIFF_KIND_GEMM_F32 = 0, ADCDIFF_KIND_GEMM_BF16 = 1, ADCDIFF_KIND_GROUPNORM = 2, ADCDIFF_KIND_UPDATE = 3 };
+enum { ADCDIFF_KIND_GEMM_F32 = 0, ADCDIFF_KIND_GEMM_BF16 = 1, ADCDIFF_KIND_GROUPNORM = 2, ADCDIFF_KIND_UPDATE = 3,
+       ADCDIFF_KIND_GEMM_BF16_T256 = 4 /* bf16 GEMM that ran on the 256 x 256-tile kernel */ };
 typedef struct adcdiff_timing_record {
     int kind;
     int M, N, K;        /* GEMM: rows, outputs, total K; others: rows, columns, 0 */
