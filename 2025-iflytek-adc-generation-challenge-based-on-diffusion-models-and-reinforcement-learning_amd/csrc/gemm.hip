@@ -16,9 +16,7 @@
 // GroupNorm is applied by the producer, so no layer output is ever re-read just to be normalised.
 #include <cstdlib>
 #ifdef ADCDIFF_STAMPS
-#include <algorithm>
 #include <cstdio>
-#include <map>
 #include <vector>
 #endif
 #include <type_traits>
@@ -484,10 +482,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
     Epi::template run<false>(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
 }
 
-// ---- 256 x 256 tile, 8 waves (2 x 4, 128 x 64 per wave), bf16 ------------------------------------------------
-// For the large layers (M, N multiples of 256).  Two 64 KiB LDS stages; the LDS-DMA of K tile t+2 is issued right
-// after the barrier that ends tile t and has the whole of tile t+1's 64 MFMAs per wave to land, so the only wait in
-// the loop finds its data already there.  One barrier per K tile, one workgroup (2 waves per SIMD) per CU.
+// ---- 256 x 256 tile, 8 waves (2 x 4, 128 x 64 per wave), bf16, one workgroup (2 waves per SIMD) per CU ----------
+// For the large layers (M, N multiples of 256).  Two 64 KiB LDS stages.
 // LDS-DMA issued from inline asm: hipcc does not track it, so it inserts no vmcnt(0) in front of the next ds_read
 // (which it does for the builtin whenever the destination may alias) and the prefetch really stays in flight
 // under the MFMAs; the loop counts vmcnt by hand.  M0 carries the wave-uniform LDS byte address and is restored.
@@ -499,11 +495,23 @@ __device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_
                  : "memory");
 }
 
+// Phased main loop: two wave groups half a phase apart.
+// A K tile (64) is four phases of 16 MFMAs per wave, one 64 x 32 quadrant of the wave's 128 x 64 tile each, in the
+// order (0,0) (0,1) (1,1) (1,0).  A phase is: ds_read the fragments it needs that are not in registers yet, issue one
+// 16 KiB region (two LDS-DMA pieces per wave) six regions ahead, wait until the region read NEXT phase has landed,
+// barrier, 16 MFMAs, barrier.  Waves 4-7 (the lower 128 rows) run one barrier behind waves 0-3, and every SIMD holds
+// one wave of each group: while one group issues its MFMAs the other does its reads and DMA issue, so the matrix pipe
+// sees back-to-back MFMA clusters instead of idling through each wave's load section.
+// Regions of a K tile, in issue order: A rows of quadrant row 0 (both groups), W rows of quadrant column 0 (all four
+// wave columns), W rows of quadrant column 1, A rows of quadrant row 1.  Phase P (= 4 * tile + quadrant) reads regions
+// P and P+1 (quadrant 0), P+1 (quadrants 1, 2) or nothing (quadrant 3: its W fragments are still in registers), and
+// issues region P+6 into the buffer of region P-2, whose last reader ran at phase P-2 or earlier and retired those
+// reads (lgkmcnt(0)) before a barrier every wave has passed since.  A region is read one phase after the counted
+// vmcnt + barrier that every wave's pieces of it have passed, never in the same phase.
 __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmParams p) {
     typedef bf16_t T;
     constexpr int BM = 256, BN = 256, WTM = 128, WTN = 64, TM = 8, TN = 4, STAGE_BYTES = 65536;
     typedef Epilogue<T, 512, BN, WTM, WTN, TM, TN> Epi;
-    static_assert(Epi::STAGE_BYTES <= 2 * STAGE_BYTES, "epilogue staging must fit the main-loop LDS");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const prm = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);
     float* const xch = prm + 5 * BN;
@@ -521,21 +529,58 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmParams p
     const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
     Epi::stage_params(p, n0, tid, prm);
 
-    // per-lane source addresses of this wave's four A pieces and four W pieces (8 rows x 128 B each) at k = 0 of the
-    // current segment; the swizzle (chunk ^ ((row >> 1) & 7)) sits in the source address, the LDS image is linear
+    // LDS-DMA geometry.  This wave's two pieces (8 rows x 128 B) of a region: A regions -- piece k = 2 * wave + j lies
+    // in wave-group row k >> 3, row group k & 7 of the 64 quadrant rows; W regions -- wave column k >> 2, row group
+    // k & 3 of the 32 quadrant rows.  The swizzle chunk ^ ((row >> 1) & 7) sits in the source address.
     const int prow = lane >> 3;
-    int a_row[4];
-    long sw[4];
-    const char* a_src[4];
-    const char* w_src[4];
+    int arow[2], wrow[2];        // tile row of this lane's piece at quadrant 0
+    long asw[2];                 // swizzled byte offset inside the 128-byte row
+    const char* wsrc[2];         // W source at K tile 0, quadrant column 0
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = 8 * (wave * 4 + j) + prow;
-        sw[j] = (long)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
-        a_row[j] = m0 + row;
-        a_src[j] = reinterpret_cast<const char*>(p.A[0]) + (long)a_row[j] * p.lda[0] * 2 + sw[j];
-        w_src[j] = reinterpret_cast<const char*>(p.W) + (long)(n0 + row) * p.ldw * 2 + sw[j];
+    for (int j = 0; j < 2; ++j) {
+        const int k = 2 * wave + j;
+        arow[j] = (k >> 3) * 128 + (k & 7) * 8 + prow;
+        wrow[j] = (k >> 2) * 64 + (k & 3) * 8 + prow;
+        asw[j] = (long)(((lane & 7) ^ ((arow[j] >> 1) & 7)) * 16);
+        wsrc[j] = reinterpret_cast<const char*>(p.W) + (long)(n0 + wrow[j]) * p.ldw * 2 + (long)(((lane & 7) ^ ((wrow[j] >> 1) & 7)) * 16);
     }
+    const int kt0 = p.ktiles[0], kt01 = p.ktiles[0] + p.ktiles[1];
+    const int nt = p.nt_total, nreg = 4 * p.nt_total;
+
+    // issue region G (tile G >> 2, kind G & 3: 0 = A quadrant row 0, 1 = W quadrant column 0, 2 = W column 1, 3 = A row 1)
+#define ADCDIFF_P_ISSUE(G)                                                                                          \
+    do {                                                                                                           \
+        const int g_ = (G);                                                                                        \
+        if (g_ < nreg) {                                                                                           \
+            const int tile_ = g_ >> 2, kind_ = g_ & 3;                                                             \
+            const unsigned sbase_ = lds0 + (tile_ & 1) * STAGE_BYTES;                                              \
+            if (kind_ == 0 || kind_ == 3) {                                                                        \
+                const int seg_ = tile_ < kt0 ? 0 : tile_ < kt01 ? 1 : 2;                                           \
+                const int kk_ = tile_ - (seg_ == 0 ? 0 : seg_ == 1 ? kt0 : kt01);                                  \
+                const char* ab_ = reinterpret_cast<const char*>(seg_ == 0 ? p.A[0] : seg_ == 1 ? p.A[1] : p.A[2]); \
+                const long ld_ = (long)(seg_ == 0 ? p.lda[0] : seg_ == 1 ? p.lda[1] : p.lda[2]) * 2;               \
+                const int q_ = kind_ == 3 ? 64 : 0;                                                                \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+                    glds16_untracked(ab_ + (long)(m0 + arow[j] + q_) * ld_ + (long)kk_ * 128 + asw[j],             \
+                                     sbase_ + (((2 * wave + j) >> 3) * 128 + q_ + ((2 * wave + j) & 7) * 8) * 128); \
+            } else {                                                                                               \
+                const int q_ = kind_ == 2 ? 32 : 0;                                                                \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+                    glds16_untracked(wsrc[j] + (long)q_ * p.ldw * 2 + (long)tile_ * 128,                           \
+                                     sbase_ + 32768 + (((2 * wave + j) >> 2) * 64 + q_ + ((2 * wave + j) & 3) * 8) * 128); \
+            }                                                                                                      \
+        }                                                                                                          \
+    } while (0)
+    // wait until this wave's pieces of region P+2 have landed: at most the regions P+3 .. min(P+6, last) stay in flight
+#define ADCDIFF_P_WAIT(P)                                                                                           \
+    do {                                                                                                           \
+        const int rem_ = nreg - 3 - (P);                                                                           \
+        if (rem_ >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                            \
+        else if (rem_ == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                       \
+        else if (rem_ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                       \
+        else if (rem_ == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                       \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+    } while (0)
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -544,72 +589,72 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmParams p
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int frow = lane & 15, fchunk = lane >> 4;
-    const int nt = p.nt_total;
+    // fragment byte offsets inside a stage: A row r of the wave tile, k half ks; the XOR depends on frow only
+    // ((row >> 1) & 7 with row = 16 * n + frow), so it is the same for every fragment row of the lane
+    const int fx = (frow >> 1) & 7;
+    const int a_off0 = (wm * WTM + frow) * 128 + ((fchunk ^ fx) << 4), a_off1 = (wm * WTM + frow) * 128 + (((4 + fchunk) ^ fx) << 4);
+    const int b_off0 = 32768 + (wn * WTN + frow) * 128 + ((fchunk ^ fx) << 4), b_off1 = 32768 + (wn * WTN + frow) * 128 + (((4 + fchunk) ^ fx) << 4);
 
-    int iseg = 0, itt = 0;   // issue cursor over the K segments
-#define ADCDIFF_ISSUE_NEXT(STAGE)                                                                          \
-    do {                                                                                                   \
-        if (itt == p.ktiles[iseg]) {                                                                       \
-            ++iseg; itt = 0;                                                                               \
-            if (itt == p.ktiles[iseg]) ++iseg;                                                             \
-            const char* nb = reinterpret_cast<const char*>(iseg == 1 ? p.A[1] : p.A[2]);                   \
-            const long nl = (long)(iseg == 1 ? p.lda[1] : p.lda[2]) * 2;                                   \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) a_src[j] = nb + (long)a_row[j] * nl + sw[j];     \
-        }                                                                                                  \
-        const unsigned sbase = lds0 + (STAGE) * STAGE_BYTES + wave * 4096;                                 \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
-            glds16_untracked(a_src[j], sbase + j * 1024);                                                  \
-            a_src[j] += 128;                                                                               \
-        }                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
-            glds16_untracked(w_src[j], sbase + 32768 + j * 1024);                                          \
-            w_src[j] += 128;                                                                               \
-        }                                                                                                  \
-        ++itt;                                                                                             \
+    uint4 fa[4][2], fb0[2][2], fb1[2][2];
+#define ADCDIFF_P_READ_A(QI, ST)                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+        fa[i][0] = *reinterpret_cast<const uint4*>((ST) + a_off0 + ((QI) * 4 + i) * 2048);                         \
+        fa[i][1] = *reinterpret_cast<const uint4*>((ST) + a_off1 + ((QI) * 4 + i) * 2048);                         \
+    }
+#define ADCDIFF_P_READ_B(FB, QJ, ST)                                                                                \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
+        FB[j][0] = *reinterpret_cast<const uint4*>((ST) + b_off0 + ((QJ) * 2 + j) * 2048);                         \
+        FB[j][1] = *reinterpret_cast<const uint4*>((ST) + b_off1 + ((QJ) * 2 + j) * 2048);                         \
+    }
+#define ADCDIFF_P_MMA(FB, QI, QJ)                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+                acc[(QI) * 4 + i][(QJ) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                         \
+                    __builtin_bit_cast(bf16x8, fa[i][ks]), __builtin_bit_cast(bf16x8, FB[j][ks]), acc[(QI) * 4 + i][(QJ) * 2 + j], 0, 0, 0)
+    // the part of a phase after its reads: DMA issue, counted wait, barrier, MFMA cluster, barrier
+#define ADCDIFF_P_BODY(P, FB, QI, QJ)                                                                               \
+    do {                                                                                                           \
+        ADCDIFF_P_ISSUE((P) + 6);                                                                                  \
+        ADCDIFF_P_WAIT(P);                                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                             \
+        ADCDIFF_P_MMA(FB, QI, QJ);                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                              \
     } while (0)
 
-    ADCDIFF_ISSUE_NEXT(0);
-    if (nt > 1) {
-        ADCDIFF_ISSUE_NEXT(1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+#pragma unroll
+    for (int g = 0; g < 6; ++g) ADCDIFF_P_ISSUE(g);
+    ADCDIFF_P_WAIT(-1);
     __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();   // the lower-rows group runs one barrier behind from here on
 #ifdef ADCDIFF_STAMPS
     const long long st1 = __builtin_amdgcn_s_memtime();
 #endif
     for (int t = 0; t < nt; ++t) {
-        const char* sa = smem + (t & 1) * STAGE_BYTES;
-        const char* sb = sa + 32768;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int c = 4 * ks + fchunk;
-            uint4 af[TM], bfr[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn * WTN + j * 16 + frow;
-                bfr[j] = *reinterpret_cast<const uint4*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * WTM + i * 16 + frow;
-                af[i] = *reinterpret_cast<const uint4*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
-                                                                        __builtin_bit_cast(bf16x8, bfr[j]), acc[i][j], 0, 0, 0);
-        }
-        // tile t+1 was issued a whole tile of MFMAs ago: this wait normally finds it landed.  The barrier then says
-        // both "every wave's part of tile t+1 is in LDS" and "every wave has finished reading stage t & 1".
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nt) ADCDIFF_ISSUE_NEXT(t & 1);
+        const char* st = smem + (t & 1) * STAGE_BYTES;
+        const int P = 4 * t;
+        ADCDIFF_P_READ_B(fb0, 0, st);
+        __builtin_amdgcn_sched_barrier(0);
+        ADCDIFF_P_READ_A(0, st);
+        ADCDIFF_P_BODY(P, fb0, 0, 0);
+        ADCDIFF_P_READ_B(fb1, 1, st);
+        ADCDIFF_P_BODY(P + 1, fb1, 0, 1);
+        ADCDIFF_P_READ_A(1, st);
+        ADCDIFF_P_BODY(P + 2, fb1, 1, 1);
+        ADCDIFF_P_BODY(P + 3, fb0, 1, 0);
     }
-#undef ADCDIFF_ISSUE_NEXT
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+#undef ADCDIFF_P_BODY
+#undef ADCDIFF_P_MMA
+#undef ADCDIFF_P_READ_B
+#undef ADCDIFF_P_READ_A
+#undef ADCDIFF_P_WAIT
+#undef ADCDIFF_P_ISSUE
     __syncthreads();
 #ifdef ADCDIFF_STAMPS
     const long long st2 = __builtin_amdgcn_s_memtime();
@@ -621,8 +666,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmParams p
     const long long st4 = __builtin_amdgcn_s_memtime(), rt4 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0 && blockIdx.x < 8192) {
         long long* o = p.stamps + ((long)blockIdx.x * 8 + wave) * 8;
-        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = rt0; o[6] = rt4;
-        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); o[7] = hw;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = rt0; o[6] = rt4; o[7] = 0;
     }
 #endif
 }
@@ -664,19 +708,6 @@ static int launch256(const GemmParams& p, hipStream_t stream) {
             const double n = (double)grid * 8;
             fprintf(stderr, "[stamps] grid %d: prologue %.0f  main %.0f  epilogue %.0f  drain %.0f cycles (mean per wave); kernel span %.1f us\n",
                     grid, pro / n, mainl / n, epi / n, drain / n, (rmax - rmin) / 100.0);
-            // per-CU busy accounting: sum of block lifetimes per CU (realtime, 100 MHz) vs the span
-            std::map<unsigned, std::vector<std::pair<long long, long long>>> cu;
-            for (int b = 0; b < grid; ++b) {
-                const long long* o = &h[((size_t)b * 8) * 8];
-                cu[(unsigned)o[7] & 0xFFFFFF00u].push_back({o[5], o[6]});
-            }
-            double gap = 0, life = 0; size_t nb = 0;
-            for (auto& kv : cu) {
-                auto& v = kv.second; std::sort(v.begin(), v.end());
-                for (size_t i = 0; i < v.size(); ++i) { life += v[i].second - v[i].first; ++nb; if (i) gap += v[i].first - v[i - 1].second; }
-            }
-            fprintf(stderr, "[stamps] %zu CU ids, mean block lifetime %.2f us, mean gap between successive blocks on a CU %.2f us\n", cu.size(),
-                    life / nb / 100.0, gap / (nb - cu.size()) / 100.0);
         }
     }
 #endif

@@ -8,7 +8,8 @@ import adcdiff
 from adcdiff import ops
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-hints = [int(h) for h in sys.argv[2].split(",")] if len(sys.argv) > 2 else [128, 256, 2561]
+hints = [int(h) for h in sys.argv[2].split(",")] if len(sys.argv) > 2 else [128, 256, 2562]
+zeros = len(sys.argv) > 3 and sys.argv[3] == "zeros"   # zero operands: shows how much of the time is the clock the chip holds on real data
 shapes = [(256, [512], 1), (256, [256, 512], 3), (512, [256], 1), (512, [512, 256], 3), (1024, [512], 1), (1024, [1024, 512], 3),
           (2048, [1024], 1), (2048, [2048, 1024], 3), (2048, [2048], 1), (2048, [2048], 2), (1024, [2048, 2048], 1),
           (1024, [1024, 2048, 2048], 2), (512, [1024, 1024], 1), (512, [512, 1024, 1024], 2), (256, [512, 512], 1),
@@ -16,8 +17,8 @@ shapes = [(256, [512], 1), (256, [256, 512], 3), (512, [256], 1), (512, [512, 25
 bf = torch.bfloat16
 tot = {h: 0.0 for h in hints}
 for N, Ks, nout in shapes:
-    As = [torch.randn(M, k, device="cuda").to(bf) for k in Ks]
-    W = (torch.randn(N, sum(Ks), device="cuda") / sum(Ks) ** 0.5).to(bf)
+    As = [(torch.zeros if zeros else torch.randn)(M, k, device="cuda").to(bf) for k in Ks]
+    W = ((torch.zeros if zeros else torch.randn)(N, sum(Ks), device="cuda") / sum(Ks) ** 0.5).to(bf)
     bias = torch.randn(N, device="cuda")
     gam, bet = torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda")
     gn = [(gam, bet, max(8, N // 32))] * min(max(nout, 0), 2)

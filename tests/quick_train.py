@@ -21,4 +21,7 @@ def run(dtype, B=4096, steps=5):
     print(f"{dtype} B={B}: {dt*1e3:.2f} ms/step, {B/dt:.0f} samples/s, {3*88.08e6*B/dt/1e12:.1f} TFLOP/s (3x forward-as-executed), losses {losses[0]:.4f} -> {losses[-1]:.4f}", flush=True)
 
 if __name__ == "__main__":
-    run("bf16"); run("fp32")
+    dts = sys.argv[1].split(",") if len(sys.argv) > 1 else ["bf16", "fp32"]
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    for d in dts:
+        run(d, B)
