@@ -65,6 +65,17 @@ class TimingRecord(C.Structure):
                 ("bytes", C.c_double)]
 
 
+class OptTensor(C.Structure):
+    _fields_ = [("param", c_fp), ("grad", c_fp), ("exp_avg", c_fp), ("exp_avg_sq", c_fp), ("numel", C.c_longlong),
+                ("chunk_start", C.c_longlong)]
+
+
+class AdamWArgs(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+                ("max_norm", C.c_double), ("step", C.c_int), ("decoupled", C.c_int)]
+
+
+OPT_CHUNK = 4096
 KIND_GEMM_F32, KIND_GEMM_BF16, KIND_GROUPNORM, KIND_UPDATE, KIND_GEMM_BF16_T256 = 0, 1, 2, 3, 4
 
 # name -> (restype, argtypes): every symbol include/adcdiff.h declares
@@ -98,6 +109,8 @@ SIGNATURES = {
     "adcdiff_unet_train_forward": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp, C.c_float, C.c_uint64, c_fp, C.c_int, c_fp, C.c_size_t, c_fp]),
     "adcdiff_mse_loss_grad": (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_float, c_fp, c_fp]),
     "adcdiff_unet_backward": (C.c_int, [c_fp, c_fp, C.c_int, C.POINTER(UnetGrads), c_fp, C.c_size_t, c_fp]),
+    "adcdiff_clip_adamw_workspace_bytes": (C.c_size_t, [C.c_longlong]),
+    "adcdiff_clip_adamw_step": (C.c_int, [c_fp, C.c_int, C.c_longlong, C.POINTER(AdamWArgs), c_fp, c_fp, C.c_size_t, c_fp]),
     "adcdiff_timing_begin": (C.c_int, [C.c_int]),
     "adcdiff_timing_end": (C.c_int, [C.POINTER(TimingRecord), C.c_int, C.POINTER(C.c_int)]),
 }

@@ -2,6 +2,8 @@
 // variance, Philox noise), DDIM update, q_sample, Philox fill, and the small table helpers.
 // Built with -ffp-contract=off so that the update formulas round exactly like the reference's
 // separate float32 torch ops.
+#include <cmath>
+
 #include "common.h"
 
 namespace adcdiff {
@@ -397,6 +399,151 @@ extern "C" int adcdiff_q_sample(const float* x0, int ldx, const int64_t* t, cons
         hipLaunchKernelGGL((q_sample_kernel<false>), grid, dim3(256), 0, as_stream(stream), x0, ldx, t, sqrt_ac, sqrt_one_minus_ac,
                            noise, ldn, out, ldo, noise_out, ldno, total4, D / 4, seed, step, row_offset);
     return check_launch("q_sample");
+}
+
+// ---------------------------------------------------------------- clip_grad_norm_ + AdamW over a tensor list
+namespace adcdiff {
+
+// chunk index -> tensor: the last descriptor whose chunk_start <= chunk (descriptors are in chunk order)
+__device__ __forceinline__ int opt_find_tensor(const adcdiff_opt_tensor* __restrict__ ts, int n, long long chunk) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ts[mid].chunk_start <= chunk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// One workgroup per chunk of ADCDIFF_OPT_CHUNK gradient elements: partial[chunk] = sum of squares, summed in a fixed
+// order (per thread in index order, then a butterfly over the wave, then the four waves in order).
+__global__ __launch_bounds__(256) void opt_sumsq_kernel(const adcdiff_opt_tensor* __restrict__ ts, int n_tensors, float* __restrict__ partial) {
+    __shared__ float wsum[4];
+    const long long chunk = blockIdx.x;
+    const adcdiff_opt_tensor d = ts[opt_find_tensor(ts, n_tensors, chunk)];
+    const long long base = (chunk - d.chunk_start) * ADCDIFF_OPT_CHUNK;
+    const long long left = d.numel - base;
+    const int cnt = left < ADCDIFF_OPT_CHUNK ? (int)left : ADCDIFF_OPT_CHUNK;
+    const float* g = d.grad + base;
+    float s = 0.0f;
+    if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
+        for (int i = threadIdx.x * 4; i + 3 < cnt; i += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
+            s += v[0] * v[0]; s += v[1] * v[1]; s += v[2] * v[2]; s += v[3] * v[3];
+        }
+        for (int i = (cnt & ~3) + threadIdx.x; i < cnt; i += 256) s += g[i] * g[i];
+    } else {
+        for (int i = threadIdx.x; i < cnt; i += 256) s += g[i] * g[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[chunk] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+
+// scal[0] = ||g||_2, scal[1] = clip factor.  One workgroup; double accumulation in a fixed order.
+__global__ __launch_bounds__(1024) void opt_norm_kernel(const float* __restrict__ partial, long long n, float max_norm, float* __restrict__ scal,
+                                                        float* __restrict__ grad_norm) {
+    __shared__ double wsum[16];
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += wsum[w];
+        const float norm = (float)sqrt(tot);
+        float clip = 1.0f;
+        if (max_norm > 0.0f) {
+            clip = max_norm / (norm + 1e-6f);   // torch.nn.utils.clip_grad_norm_: clamp(max_norm / (total_norm + 1e-6), max=1)
+            clip = clip > 1.0f ? 1.0f : clip;
+        }
+        scal[0] = norm; scal[1] = clip;
+        if (grad_norm) *grad_norm = norm;
+    }
+}
+
+struct OptScalars { float decay, w1, beta2, w2, inv_bc2_sqrt, eps, neg_step, l2; };
+
+__device__ __forceinline__ void opt_update1(float& p, float g, float& m, float& v, float clip, const OptScalars& c) {
+    g = g * clip;
+    if (c.l2 != 0.0f) g = g + c.l2 * p;        // Adam: grad.add(param, alpha=weight_decay)
+    p = p * c.decay;                            // AdamW: param.mul_(1 - lr * weight_decay); decay = 1 for Adam
+    m = m + c.w1 * (g - m);                     // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * c.beta2;                            // exp_avg_sq.mul_(beta2)
+    v = v + c.w2 * (g * g);                     //           .addcmul_(grad, grad, value=1 - beta2)
+    const float denom = __builtin_sqrtf(v) * c.inv_bc2_sqrt + c.eps;   // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
+    p = p + c.neg_step * (m / denom);           // param.addcdiv_(exp_avg, denom, value=-lr / bias_correction1)
+}
+
+__global__ __launch_bounds__(256) void opt_adamw_kernel(const adcdiff_opt_tensor* __restrict__ ts, int n_tensors, const float* __restrict__ scal,
+                                                        const OptScalars c) {
+    const long long chunk = blockIdx.x;
+    const adcdiff_opt_tensor d = ts[opt_find_tensor(ts, n_tensors, chunk)];
+    const long long base = (chunk - d.chunk_start) * ADCDIFF_OPT_CHUNK;
+    const long long left = d.numel - base;
+    const int cnt = left < ADCDIFF_OPT_CHUNK ? (int)left : ADCDIFF_OPT_CHUNK;
+    const float clip = scal[1];
+    float* p = d.param + base;
+    const float* g = d.grad + base;
+    float* m = d.exp_avg + base;
+    float* v = d.exp_avg_sq + base;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                       reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
+    if (vec) {
+        for (int i = threadIdx.x * 4; i + 3 < cnt; i += 1024) {
+            f32x4 pv = *reinterpret_cast<f32x4*>(p + i), mv = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = pv[e], me = mv[e], ve = vv[e];
+                opt_update1(pe, gv[e], me, ve, clip, c);
+                pv[e] = pe; mv[e] = me; vv[e] = ve;
+            }
+            *reinterpret_cast<f32x4*>(p + i) = pv;
+            *reinterpret_cast<f32x4*>(m + i) = mv;
+            *reinterpret_cast<f32x4*>(v + i) = vv;
+        }
+    }
+    for (int i = (vec ? (cnt & ~3) : 0) + threadIdx.x; i < cnt; i += 256) opt_update1(p[i], g[i], m[i], v[i], clip, c);
+}
+
+}  // namespace adcdiff
+
+extern "C" size_t adcdiff_clip_adamw_workspace_bytes(long long total_chunks) {
+    return total_chunks <= 0 ? 0 : (size_t)total_chunks * 4 + 256;
+}
+
+extern "C" int adcdiff_clip_adamw_step(const adcdiff_opt_tensor* tensors, int n_tensors, long long total_chunks, const adcdiff_adamw_args* a,
+                                       float* grad_norm, void* workspace, size_t workspace_bytes, adcdiff_stream_t stream_) {
+    using namespace adcdiff;
+    if (!tensors || !a || n_tensors <= 0 || total_chunks <= 0 || total_chunks > 0x7fffffffLL)
+        return fail(ADCDIFF_E_BADARG, "clip_adamw_step: null table / args or %d tensors, %lld chunks", n_tensors, total_chunks);
+    if (!workspace || !aligned16(workspace) || workspace_bytes < adcdiff_clip_adamw_workspace_bytes(total_chunks))
+        return fail(ADCDIFF_E_WORKSPACE, "clip_adamw_step: workspace of %zu bytes, %zu needed", workspace_bytes,
+                    adcdiff_clip_adamw_workspace_bytes(total_chunks));
+    if (a->step < 1 || !(a->beta1 >= 0.0 && a->beta1 < 1.0) || !(a->beta2 >= 0.0 && a->beta2 < 1.0) || !(a->eps >= 0.0))
+        return fail(ADCDIFF_E_BADARG, "clip_adamw_step: step %d, betas (%g, %g), eps %g", a->step, a->beta1, a->beta2, a->eps);
+    hipStream_t st = as_stream(stream_);
+    float* scal = reinterpret_cast<float*>(workspace);          // [0] norm, [1] clip factor
+    float* partial = scal + 64;
+    hipLaunchKernelGGL(opt_sumsq_kernel, dim3((unsigned)total_chunks), dim3(256), 0, st, tensors, n_tensors, partial);
+    hipLaunchKernelGGL(opt_norm_kernel, dim3(1), dim3(1024), 0, st, partial, total_chunks, (float)a->max_norm, scal, grad_norm);
+    // scalars as torch forms them: python floats (double) rounded to float where they meet the float32 tensors
+    const double bc1 = 1.0 - pow(a->beta1, a->step), bc2 = 1.0 - pow(a->beta2, a->step);
+    OptScalars c;
+    c.decay = a->decoupled ? (float)(1.0 - a->lr * a->weight_decay) : 1.0f;
+    c.l2 = a->decoupled ? 0.0f : (float)a->weight_decay;
+    c.w1 = (float)(1.0 - a->beta1);
+    c.beta2 = (float)a->beta2;
+    c.w2 = (float)(1.0 - a->beta2);
+    c.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    c.eps = (float)a->eps;
+    c.neg_step = (float)(-a->lr / bc1);
+    hipLaunchKernelGGL(opt_adamw_kernel, dim3((unsigned)total_chunks), dim3(256), 0, st, tensors, n_tensors, scal, c);
+    return check_launch("clip_adamw_step");
 }
 
 extern "C" int adcdiff_timing_begin(int max_records) {

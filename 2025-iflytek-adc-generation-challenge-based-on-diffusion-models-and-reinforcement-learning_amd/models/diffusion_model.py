@@ -426,6 +426,7 @@ class DiffusionModel(nn.Module):
         optimizer_class = AdamW if config.get('use_adamw', True) else Adam
         self.optimizer = optimizer_class(self.model.parameters(), lr=config.get('learning_rate', 1e-4),
                                          weight_decay=config.get('weight_decay', 1e-2))
+        self._fused_opt = None
         if config.get('use_onecycle', False):
             self.scheduler = OneCycleLR(self.optimizer, max_lr=config.get('learning_rate', 1e-4),
                                         total_steps=config.get('total_steps', 10000))
@@ -656,8 +657,8 @@ class DiffusionModel(nn.Module):
     def train_step(self, x: torch.Tensor, step: int = 0) -> Dict[str, float]:
         """diffusion_model.py:401-471: random timesteps, noise-prediction loss, backward, clip_grad_norm_(1.0), optimizer step,
         with the reference's gradient accumulation and chunking above max_batch_size.  Forward and backward of the denoiser
-        run in the HIP library; gradient clipping and AdamW are torch's (the optimizer object and its state_dict are part
-        of the reference's checkpoint format)."""
+        run in the HIP library, and so do gradient clipping and the AdamW arithmetic (optim.FusedClipAdamW) on the state
+        tensors of the torch optimizer object, whose state_dict is part of the reference's checkpoint format."""
         self.operation_count += 1
         self.model.train()
         batch_size = x.shape[0]
@@ -673,8 +674,10 @@ class DiffusionModel(nn.Module):
             # clipped norm and the AdamW step are identical on every rank; a no-op in a single process
             from ..parallel import allreduce_gradients
             allreduce_gradients(self.model.parameters())
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=1.0)
-            self.optimizer.step()
+            if self._fused_opt is None or self._fused_opt.optimizer is not self.optimizer:
+                from ..optim import FusedClipAdamW
+                self._fused_opt = FusedClipAdamW(self.optimizer, max_norm=1.0)
+            self._fused_opt.step()     # clip_grad_norm_(max_norm=1.0) + optimizer.step() in three launches
             self.optimizer.zero_grad()
         memory_info = self._get_memory_usage()
         return {

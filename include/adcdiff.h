@@ -229,6 +229,38 @@ int adcdiff_mse_loss_grad(const float* pred, int ldp, const float* target, int l
 int adcdiff_unet_backward(adcdiff_unet* net, const float* d_eps, int lde, const adcdiff_unet_grads* grads, void* workspace,
                           size_t workspace_bytes, adcdiff_stream_t stream);
 
+/* ------------------------------------------------------------------ optimizer step ------ */
+
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by optimizer.step() of AdamW / Adam
+ * (diffusion_model.py:69-74 construction, :434-436 and :456-459 use) over all parameter tensors in three launches:
+ * per-chunk sums of squares of the gradients, a fixed-order reduction to the global L2 norm and
+ * clip = min(1, max_norm / (norm + 1e-6)), and the update
+ *   g = clip * grad (+ weight_decay * p when decoupled == 0: Adam's L2 form)
+ *   p *= 1 - lr * weight_decay (decoupled != 0: AdamW);  m += (1 - beta1) * (g - m);  v = beta2 * v + (1 - beta2) * g * g
+ *   p -= (lr / bias_correction1) * m / (sqrt(v) / sqrt(bias_correction2) + eps),  bias_correction_i = 1 - beta_i^step
+ * in torch's operation order.  No host synchronisation; deterministic (fixed chunking, fixed summation order).
+ * `tensors` is a DEVICE array of n_tensors descriptors (the caller uploads it once and again when a pointer changes);
+ * chunk_start = number of ADCDIFF_OPT_CHUNK-element chunks in all earlier tensors.  grad_norm (device, optional)
+ * receives the norm before clipping, as clip_grad_norm_ returns it. */
+#define ADCDIFF_OPT_CHUNK 4096
+typedef struct adcdiff_opt_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    long long numel;
+    long long chunk_start;
+} adcdiff_opt_tensor;
+typedef struct adcdiff_adamw_args {
+    double lr, beta1, beta2, eps, weight_decay;   /* the optimizer's python floats: 1 - beta2 must not pass through float32 */
+    double max_norm;       /* <= 0: no clipping */
+    int step;              /* 1-based count of this update */
+    int decoupled;         /* 1 = AdamW, 0 = Adam with L2 weight decay */
+} adcdiff_adamw_args;
+size_t adcdiff_clip_adamw_workspace_bytes(long long total_chunks);
+int adcdiff_clip_adamw_step(const adcdiff_opt_tensor* tensors, int n_tensors, long long total_chunks, const adcdiff_adamw_args* args,
+                            float* grad_norm, void* workspace, size_t workspace_bytes, adcdiff_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement ------ */
 
 /* Per-launch timing for benchmarks; no counterpart in the reference.  Between adcdiff_timing_begin and

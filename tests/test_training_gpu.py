@@ -102,9 +102,16 @@ def test_training_reduces_loss_with_dropout_and_accumulation(dtype):
     torch.manual_seed(0)
     m = build(dtype, learning_rate=1e-3, max_batch_size=256, gradient_accumulation_steps=1)
     x = cu(philox.normal(7, 52, 0, 0, 512, 128))
+    t_fix = torch.arange(512, device="cuda") % 1000
+    nz_fix = cu(philox.normal(7, 53, 0, 0, 512, 128))
+    m.model.eval()
+    before = float(m.p_losses(x, t_fix, noise=nz_fix).detach())
     losses = [m.train_step(x, s)["loss"] for s in range(8)]
     assert all(np.isfinite(losses))
     assert losses[-1] < losses[0]
+    m.model.eval()
+    after = float(m.p_losses(x, t_fix, noise=nz_fix).detach())
+    assert after < 0.99 * before   # same timesteps and noise: the optimiser's updates reached the packed weights the kernels read
     out = m.sample(4, use_ddim=False, seed=1, t_start=999, t_stop=990)   # the packed weights follow the optimiser
     assert torch.isfinite(out).all()
 
@@ -143,3 +150,51 @@ def test_large_batch_gradient_is_mean_of_half_batch_gradients(dtype):
         ref = 0.5 * (g_a[k] + g_b[k])
         assert torch.isfinite(ga).all(), k
         assert float((ga - ref).abs().max()) <= tol * max(float(ref.abs().max()), 1e-6), k
+
+
+@pytest.mark.parametrize("opt_cls", ["AdamW", "Adam"])
+def test_fused_clip_adamw_matches_torch(opt_cls):
+    """clip_grad_norm_(1.0) + optimizer.step() of torch against the three-launch version on the same tensors: ragged sizes
+    (1 element, not a multiple of 4, several chunks), three steps, gradients large enough for the clip to act on step 1 and
+    small enough not to on step 3.  Tolerance: the update is lr * m / (sqrt(v) + eps) with |m / sqrt(v)| <= ~1, so 1e-3
+    of lr = 1e-6 absolute covers the differing fma contraction of the two implementations; moments 1e-5 relative or 1e-6
+    of the tensor's largest entry."""
+    from adcdiff.optim import FusedClipAdamW
+    sizes = [(1,), (7,), (130, 33), (4096,), (257, 129), (3, 5, 7), (64, 1024)]
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    init = [torch.randn(*sz, generator=gen) for sz in sizes]
+    grads = [[torch.randn(*sz, generator=gen) * scale for sz in sizes] for scale in (1.0, 0.05, 0.001)]
+    cls = getattr(torch.optim, opt_cls)
+
+    def run(fused):
+        params = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+        opt = cls(params, lr=1e-3, weight_decay=1e-2)
+        f = FusedClipAdamW(opt, max_norm=1.0) if fused else None
+        norms = []
+        for gs in grads:
+            for p_, g_ in zip(params, gs):
+                p_.grad = g_.clone().cuda()
+            if fused:
+                norms.append(float(f.step()))
+            else:
+                norms.append(float(torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)))
+                opt.step()
+            opt.zero_grad()
+        return params, opt, norms
+
+    pa, oa, na = run(False)
+    pb, ob, nb = run(True)
+    assert np.allclose(na, nb, rtol=2e-6)
+    assert na[0] > 1.0 > na[2]   # the clip acts on the first step only
+    for a, b in zip(pa, pb):
+        assert float((a.detach() - b.detach()).abs().max()) <= 1e-6
+        sa, sb = oa.state[a], ob.state[b]
+        assert float(sa["step"]) == float(sb["step"]) == 3.0
+        for k in ("exp_avg", "exp_avg_sq"):
+            # entries that nearly cancel carry the rounding of their terms: absolute bound from the tensor's scale
+            assert torch.allclose(sa[k], sb[k], rtol=1e-5, atol=1e-6 * float(sa[k].abs().max())), k
+    assert all(p_._version >= 3 for p_ in pb)   # every fused step is visible to whoever caches data derived from the parameters
+    # the state the fused step leaves is a torch optimizer state: it round-trips through state_dict / load_state_dict
+    sd = ob.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    ob.load_state_dict(sd)
