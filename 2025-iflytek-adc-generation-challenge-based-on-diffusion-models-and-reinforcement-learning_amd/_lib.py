@@ -109,6 +109,7 @@ SIGNATURES = {
     "adcdiff_unet_train_forward": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp, C.c_float, C.c_uint64, c_fp, C.c_int, c_fp, C.c_size_t, c_fp]),
     "adcdiff_mse_loss_grad": (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_float, c_fp, c_fp]),
     "adcdiff_unet_backward": (C.c_int, [c_fp, c_fp, C.c_int, C.POINTER(UnetGrads), c_fp, C.c_size_t, c_fp]),
+    "adcdiff_latent_summary": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp]),
     "adcdiff_clip_adamw_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "adcdiff_clip_adamw_step": (C.c_int, [c_fp, C.c_int, C.c_longlong, C.POINTER(AdamWArgs), c_fp, c_fp, C.c_size_t, c_fp]),
     "adcdiff_timing_begin": (C.c_int, [C.c_int]),

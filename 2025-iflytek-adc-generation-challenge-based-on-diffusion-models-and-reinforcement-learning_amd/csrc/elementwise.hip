@@ -401,6 +401,63 @@ extern "C" int adcdiff_q_sample(const float* x0, int ldx, const int64_t* t, cons
     return check_launch("q_sample");
 }
 
+// ---------------------------------------------------------------- latent summaries (numpy-ordered row sums)
+namespace adcdiff {
+
+// One wave per row.  Lane (leaf, j) = (lane >> 3, lane & 7) accumulates numpy's partial sum r[j] of 128-element block
+// `leaf` (a[j] + a[8 + j] + ... in index order); xor-shuffles 1, 2, 4 combine the eight partial sums in numpy's order,
+// 8, 16, 32 the blocks as a balanced tree; rows longer than 1024 take several passes combined the same way.
+__global__ __launch_bounds__(256) void latent_summary_kernel(const float* __restrict__ x, long ldx, int B, int D, float* __restrict__ out, long ldo) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int lane = threadIdx.x & 63, leaf = lane >> 3, j = lane & 7;
+    const float* a = x + (long)row * ldx;
+    const int nleaf = D >> 7;                 // 1, 2, 4, 8, 16 or 32
+    const int passes = nleaf > 8 ? nleaf >> 3 : 1;
+    float pass_sum[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        pass_sum[ps] = 0.0f;
+        if (ps < passes) {
+            const int lf = ps * 8 + leaf;
+            float r = 0.0f;
+            if (lf < nleaf) {
+                const float* b = a + lf * 128 + j;
+                r = b[0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) r += b[8 * i];
+            }
+            r += __shfl_xor(r, 1);
+            r += __shfl_xor(r, 2);
+            r += __shfl_xor(r, 4);
+            if (nleaf >= 2) r += __shfl_xor(r, 8);
+            if (nleaf >= 4) r += __shfl_xor(r, 16);
+            if (nleaf >= 8) r += __shfl_xor(r, 32);
+            pass_sum[ps] = r;
+        }
+    }
+    float sum = pass_sum[0];
+    if (passes == 2) sum = pass_sum[0] + pass_sum[1];
+    if (passes == 4) sum = (pass_sum[0] + pass_sum[1]) + (pass_sum[2] + pass_sum[3]);
+    if (lane == 0) {
+        float* o = out + (long)row * ldo;
+        o[0] = sum / (float)D;
+        o[1] = sum;
+        o[2] = a[3]; o[3] = a[5]; o[4] = a[8];
+    }
+}
+
+}  // namespace adcdiff
+
+extern "C" int adcdiff_latent_summary(const float* x, int ldx, int B, int D, float* out, int ld_out, adcdiff_stream_t stream_) {
+    using namespace adcdiff;
+    if (!x || !out || B <= 0 || ldx < D || ld_out < 5) return fail(ADCDIFF_E_BADARG, "latent_summary: null pointers, B=%d, ldx=%d < D or ld_out=%d < 5", B, ldx, ld_out);
+    if (D < 128 || D > 4096 || (D & (D - 1)) != 0)
+        return fail(ADCDIFF_E_BADARG, "latent_summary: D=%d; numpy's pairwise order is reproduced for D = 128 * 2^k up to 4096", D);
+    hipLaunchKernelGGL(latent_summary_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream_), x, (long)ldx, B, D, out, (long)ld_out);
+    return check_launch("latent_summary");
+}
+
 // ---------------------------------------------------------------- clip_grad_norm_ + AdamW over a tensor list
 namespace adcdiff {
 

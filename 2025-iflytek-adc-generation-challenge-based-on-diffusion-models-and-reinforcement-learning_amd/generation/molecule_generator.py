@@ -2,8 +2,10 @@
 
 Only the part that drives the diffusion model is mirrored: batching by ``generation_batch_size``, expanding
 a 1-row protein condition to the batch, calling ``DiffusionModel.sample`` (DDIM, 50 steps by default) under
-``no_grad``.  Everything downstream of the latents in the reference (latent -> SMILES heuristic, RDKit
-validation and scoring, the RL edit loop, :273-2278) is CPU cheminformatics outside this package.
+``no_grad``, and the reduction of a latent row to the five numbers the reference's latent -> SMILES heuristic
+reads (:1072-1163), done on the GPU so that 20 bytes per sample are copied to the host instead of the row.
+Everything that needs RDKit (validation, scoring, the RL edit loop, :273-2278) is CPU cheminformatics outside
+this package.
 """
 import logging
 import time
@@ -11,7 +13,12 @@ from typing import Dict, List, Optional
 
 import torch
 
+from .. import ops
 from ..models.diffusion_model import DiffusionModel
+
+# molecule_generator.py:1140-1156, in order
+DRUG_LIKE_SMILES = ("CCO", "CC(=O)O", "c1ccccc1", "c1ccc(O)cc1", "c1ccc(N)cc1", "CCN", "CC(C)O", "CCCC", "c1ccc(C)cc1", "CC(=O)N",
+                    "c1ccc(Cl)cc1", "CCc1ccccc1", "CC(C)(C)O", "c1ccc2ccccc2c1", "CC(=O)c1ccccc1")
 
 
 class MoleculeGenerator:
@@ -77,5 +84,37 @@ class MoleculeGenerator:
         self.logger.info("generated %d latent vectors in %.2fs", num_molecules, time.time() - start)
         return torch.cat(chunks, dim=0)
 
+    def latent_summaries(self, features: torch.Tensor) -> torch.Tensor:
+        """[N, D] latents on the GPU -> [N, 5] float32 (mean, sum, f[3], f[5], f[8]) per row, in numpy's float32 summation
+        order: everything _decode_features_to_smiles / _add_functional_groups / _generate_fallback_smiles
+        (molecule_generator.py:1072-1163) read of a row."""
+        return ops.latent_summary(features.to(torch.float32))
+
+    @staticmethod
+    def smiles_candidates(summary_row, n_features: int = 512):
+        """(primary, fallback) strings for one summary row.  primary = _add_functional_groups(base) over the base chosen
+        by the mean thresholds (molecule_generator.py:1084-1126); fallback = the drug-like table entry selected by
+        int(|sum| * 15) % 15 (:1158-1161).  The reference returns primary when RDKit validates it and fallback otherwise
+        (:1062-1066); that check stays with the caller."""
+        mean, total, f3, f5, f8 = (float(v) for v in summary_row)
+        if mean > 0.5:
+            base = "c1ccccc1"
+        elif mean > 0.3:
+            base = "CCCCCC"
+        elif mean > 0.1:
+            base = "CCO"
+        else:
+            base = "CC"
+        primary = base
+        if n_features > 10:
+            if f5 > 0.7:
+                primary = "c1ccc(O)cc1" if "c1ccccc1" in base else base + "O"
+            elif f8 > 0.6:
+                primary = "c1ccc(N)cc1" if "c1ccccc1" in base else base + "N"
+            elif f3 > 0.8:
+                primary = base + "C(=O)O"
+        return primary, DRUG_LIKE_SMILES[int(abs(total) * len(DRUG_LIKE_SMILES)) % len(DRUG_LIKE_SMILES)]
+
     def _features_to_smiles(self, features):
-        raise NotImplementedError("latent -> SMILES decoding needs RDKit and is outside the diffusion hot path")
+        raise NotImplementedError("validated latent -> SMILES decoding needs RDKit and is outside the diffusion hot path; "
+                                  "latent_summaries + smiles_candidates give its RDKit-free part")

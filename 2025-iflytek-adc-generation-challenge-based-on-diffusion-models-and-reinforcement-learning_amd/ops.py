@@ -163,6 +163,19 @@ def q_sample(x0, t, sqrt_ac, sqrt_1mac, noise=None, seed=0, step=0, row_offset=0
     return (out, nz_out) if return_noise else out
 
 
+def latent_summary(x):
+    """[B, D] float32 latents -> [B, 5] float32 (mean, sum, x[:, 3], x[:, 5], x[:, 8]) with numpy's float32 summation order."""
+    lib = _lib.load()
+    _need_gpu(x)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("latent_summary expects a [B, D] float32 tensor with contiguous rows")
+    B, D = x.shape
+    out = torch.empty((B, 5), device=x.device, dtype=torch.float32)
+    if B:
+        check(lib.adcdiff_latent_summary(_ptr(x), x.stride(0), B, D, _ptr(out), 5, _stream()))
+    return out
+
+
 class timing:
     """Context manager over adcdiff_timing_begin/_end: ``with ops.timing(4096) as t: ...; t.records``."""
 

@@ -55,11 +55,21 @@ def sample_sharded(sample_fn: Callable[[int, int], torch.Tensor], total: int, gr
 
 
 def sample_ddpm_sharded(model, total: int, condition: Optional[torch.Tensor] = None, seed: int = 0, use_ddim: bool = False,
-                        ddim_steps: int = 50, eta: float = 0.0, group=None) -> torch.Tensor:
-    """Shard `total` samples of model.sample over the process group; condition is [total, D], [1, D] or [D]."""
+                        ddim_steps: int = 50, eta: float = 0.0, group=None, summaries: bool = False) -> torch.Tensor:
+    """Shard `total` samples of model.sample over the process group; condition is [total, D], [1, D] or [D].
+
+    summaries=True gathers, instead of the [total, D] latents, the five numbers per row that the reference's
+    latent -> SMILES heuristic reads (ops.latent_summary: mean, sum, x[3], x[5], x[8]): 20 bytes per sample over xGMI
+    instead of 4 * D, and the same 20 bytes for the host copy that follows."""
     def run(count, first):
         if count == 0:
-            return torch.empty((0, model.output_dim), device=model.device, dtype=torch.float32)
+            return torch.empty((0, 5 if summaries else model.output_dim), device=model.device, dtype=torch.float32)
+        if summaries:
+            from . import ops
+            return ops.latent_summary(run_latents(count, first))
+        return run_latents(count, first)
+
+    def run_latents(count, first):
         cond = None
         if condition is not None:
             cond = condition

@@ -229,6 +229,17 @@ int adcdiff_mse_loss_grad(const float* pred, int ldp, const float* target, int l
 int adcdiff_unet_backward(adcdiff_unet* net, const float* d_eps, int lde, const adcdiff_unet_grads* grads, void* workspace,
                           size_t workspace_bytes, adcdiff_stream_t stream);
 
+/* ------------------------------------------------------------------ latent summaries ------ */
+
+/* What the reference's latent -> SMILES heuristic reads of a latent row (molecule_generator.py:1080-1082 np.sum /
+ * np.mean of the float32 row, :1114-1126 features[5], [8], [3], :1158-1161 the fallback's np.sum):
+ *   out[row] = { mean, sum, x[3], x[5], x[8] }    (5 floats, ld_out >= 5)
+ * so that 20 bytes per sample leave the GPU (or cross xGMI) instead of the 4 * D byte row.  The sum reproduces
+ * numpy's float32 pairwise summation bit for bit (blocks of 128 elements, eight strided partial sums per block combined
+ * as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), blocks combined as a balanced binary tree), which is defined here for
+ * D = 128 * 2^k, 128 <= D <= 4096 (the tree is then perfect); other D are rejected.  mean = sum / D. */
+int adcdiff_latent_summary(const float* x, int ldx, int B, int D, float* out, int ld_out, adcdiff_stream_t stream);
+
 /* ------------------------------------------------------------------ optimizer step ------ */
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by optimizer.step() of AdamW / Adam

@@ -210,3 +210,24 @@ def test_ddim_and_q_sample_bit_exact():
     out, used = ops.q_sample(_t(x), _t(t, torch.int64), _t(s["sqrt_alpha_cumprod"]), _t(s["sqrt_one_minus_alpha_cumprod"]),
                              seed=9, step=4, row_offset=2, return_noise=True)
     assert np.abs(used.cpu().numpy() - philox.normal(9, philox.STREAM_QNOISE, 4, 2, B, D)).max() < 4e-6
+
+
+@pytest.mark.parametrize("D", [128, 512, 1024, 4096])
+def test_latent_summary_is_numpy_bit_for_bit(D):
+    """(mean, sum, x[3], x[5], x[8]) per row against numpy's own float32 np.mean / np.sum (the arithmetic of
+    molecule_generator.py:1080-1081, :1160): bit-exact, on rows of mixed magnitude and sign, through a strided view."""
+    from oracle import latent
+    rng = np.random.default_rng(D)
+    B = 203
+    x = (rng.standard_normal((B, D)) * 10.0 ** rng.uniform(-3, 3, size=(B, 1))).astype(np.float32)
+    x[5] = 0.0
+    x[6, :] = 1e-30
+    xt = torch.from_numpy(np.concatenate([x, np.zeros((B, 16), np.float32)], axis=1)).cuda()[:, :D]   # row stride D + 16
+    got = ops.latent_summary(xt).cpu().numpy()
+    ref = latent.summaries(x)
+    assert got.shape == (B, 5) and got.tobytes() == ref.tobytes()
+
+
+def test_latent_summary_rejects_unsupported_width():
+    with pytest.raises(Exception, match="128"):
+        ops.latent_summary(torch.zeros(4, 320, device="cuda"))

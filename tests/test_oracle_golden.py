@@ -144,3 +144,27 @@ def test_full_size_configs(name, dims, golden_tiny):
     assert rel_err(out[:, cols], g["loop_T1000.values"][:rows]) < LOOP_TOL
     out = ddpm.ddim_sample_loop(w, s, ddpm.philox_x_T(NOISE_SEED, 0, rows, 512), None, 50, 0.0)
     assert rel_err(out[:, cols], g["ddim50.values"][:rows]) < LOOP_TOL
+
+
+def test_latent_pairwise_restatement_is_numpy_sum():
+    """The summation order written out in oracle.latent.pairwise_sum_f32 (the order the GPU kernel reproduces) is np.sum's."""
+    from oracle import latent
+    rng = np.random.default_rng(1)
+    for n in (5, 8, 100, 128, 512, 1000, 4096):
+        for _ in range(5):
+            a = (rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 3)).astype(np.float32)
+            assert latent.pairwise_sum_f32(a).tobytes() == np.sum(a).tobytes()
+
+
+def test_smiles_candidates_follow_the_reference_thresholds():
+    """Host half of the latent -> SMILES heuristic (molecule_generator.py:1084-1126, :1158-1161), product code against
+    the oracle's restatement on summary rows around every threshold."""
+    from oracle import latent
+    import adcdiff
+    from adcdiff.generation.molecule_generator import MoleculeGenerator
+    rows = [(m, s, f3, f5, f8) for m in (0.05, 0.1, 0.2, 0.31, 0.5, 0.6) for s in (-3.3, 0.0, 0.07, 12.9)
+            for f3, f5, f8 in ((0.9, 0.0, 0.0), (0.0, 0.71, 0.9), (0.0, 0.0, 0.61), (0.8, 0.7, 0.6))]
+    for r in rows:
+        assert MoleculeGenerator.smiles_candidates(r) == latent.decode_candidates(r)
+    assert MoleculeGenerator.smiles_candidates((0.6, 0.0, 0.0, 0.9, 0.0)) == ("c1ccc(O)cc1", "CCO")
+    assert MoleculeGenerator.smiles_candidates((0.2, 1.0, 0.9, 0.0, 0.0))[0] == "CCOC(=O)O"
