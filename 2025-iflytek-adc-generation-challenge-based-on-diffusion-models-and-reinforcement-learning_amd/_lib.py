@@ -20,7 +20,8 @@ class GemmArgs(C.Structure):
                 ("A", c_fp * 3), ("lda", C.c_int * 3), ("K", C.c_int * 3), ("W", c_fp), ("ldw", C.c_int),
                 ("bias", c_fp), ("rowbias", c_fp), ("ldrb", C.c_longlong), ("rowbias_idx", c_fp),
                 ("residual", c_fp), ("ldr", C.c_int), ("act", C.c_int), ("out_f32", c_fp), ("ldo_f32", C.c_int),
-                ("out_op", c_fp), ("ldo_op", C.c_int), ("n_gn", C.c_int), ("gn", GnOut * 2), ("gn_eps", C.c_float), ("tile_hint", C.c_int)]
+                ("out_op", c_fp), ("ldo_op", C.c_int), ("n_gn", C.c_int), ("gn", GnOut * 2), ("gn_eps", C.c_float), ("tile_hint", C.c_int),
+                ("split_k", C.c_int), ("split_stride", C.c_longlong)]
 
 
 class DdpmCoef(C.Structure):

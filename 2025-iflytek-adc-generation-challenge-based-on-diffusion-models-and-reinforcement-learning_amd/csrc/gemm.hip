@@ -54,6 +54,9 @@ struct GemmParams {
     int n_gn;
     GnOut gn[2];
     float eps;
+    int ksplit;                  // grid.y: K slices (1 without split-K)
+    long long split_k_bytes;     // byte offset along K of slice blockIdx.y (0 without split-K)
+    long long split_out_stride;  // floats between the partial outputs of consecutive slices
 #ifdef ADCDIFF_STAMPS
     long long* stamps;
 #endif
@@ -272,7 +275,7 @@ struct Epilogue {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = silu_f(v[k]);
         }
-        if (p.out_f32 && live) store8<float>(p.out_f32 + row * p.ldo_f32 + col, v);
+        if (p.out_f32 && live) store8<float>(p.out_f32 + (long)blockIdx.y * p.split_out_stride + row * p.ldo_f32 + col, v);
         if (p.out_op && live) store8<T>(reinterpret_cast<T*>(p.out_op) + row * p.ldo_op + col, v);
         float* const xch = xch_base + (step_id & 1) * (2 * XB);
         if (p.n_gn > 0) {
@@ -394,7 +397,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
         const int row = 8 * (wave * B_PIECES + j) + prow;
         b_off[j] = (long)(n0 + row) * p.ldw * (long)sizeof(T) + (long)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
     }
-    const char* const Wb = reinterpret_cast<const char*>(p.W);
+    const long ksb = (long)blockIdx.y * p.split_k_bytes;   // split-K: this workgroup's slice of the (single) K segment
+    const char* const Wb = reinterpret_cast<const char*>(p.W) + ksb;
 
     typedef float acc_t __attribute__((ext_vector_type(NACC)));
     acc_t acc[TM][TN];
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
     const int fchunk = BF ? (lane >> 4) : (lane >> 5);
 
     int seg = 0, tt = 0;
-    const char* Ab = reinterpret_cast<const char*>(p.A[0]);
+    const char* Ab = reinterpret_cast<const char*>(p.A[0]) + ksb;
     long lda_b = (long)p.lda[0] * (long)sizeof(T);
     for (int t = 0; t < p.nt_total; ++t, ++tt) {
         if (tt == p.ktiles[seg]) {   // next K segment (wave-uniform)
@@ -542,7 +546,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmParams p
         arow[j] = (k >> 3) * 128 + (k & 7) * 8 + prow;
         wrow[j] = (k >> 2) * 64 + (k & 3) * 8 + prow;
         asw[j] = (long)(((lane & 7) ^ ((arow[j] >> 1) & 7)) * 16);
-        wsrc[j] = reinterpret_cast<const char*>(p.W) + (long)(n0 + wrow[j]) * p.ldw * 2 + (long)(((lane & 7) ^ ((wrow[j] >> 1) & 7)) * 16);
+        wsrc[j] = reinterpret_cast<const char*>(p.W) + (long)(n0 + wrow[j]) * p.ldw * 2 + (long)(((lane & 7) ^ ((wrow[j] >> 1) & 7)) * 16) +
+                  (long)blockIdx.y * p.split_k_bytes;
+        asw[j] += (long)blockIdx.y * p.split_k_bytes;   // split-K slice of the (single) K segment
     }
     const int kt0 = p.ktiles[0], kt01 = p.ktiles[0] + p.ktiles[1];
     const int nt = p.nt_total, nreg = 4 * p.nt_total;
@@ -687,7 +693,7 @@ static int launch256(const GemmParams& p, hipStream_t stream) {
     q.stamps = dbuf;
 #endif
     const int grid = (p.M / 256) * q.ntn;
-    hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(grid), dim3(512), smem, stream, q);
+    hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(grid, p.ksplit), dim3(512), smem, stream, q);
 #ifdef ADCDIFF_STAMPS
     {
         static int calls = 0;
@@ -730,7 +736,7 @@ static int launch(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     q.ntn = p.N / BN;
     const int grid = (p.M / BM) * q.ntn;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN>), dim3(grid), dim3(256), smem, stream, q);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN>), dim3(grid, p.ksplit), dim3(256), smem, stream, q);
     return check_launch("gemm");
 }
 
@@ -781,7 +787,19 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         p.gn[g] = GnOut{o.gamma, o.beta, o.out, o.ldo, gs};
     }
     p.n_gn = a.n_gn; p.eps = a.gn_eps;
-    p.W = a.W; p.ldw = a.ldw; p.M = a.M; p.N = a.N; p.nt_total = ktot / bk;
+    p.ksplit = 1; p.split_k_bytes = 0; p.split_out_stride = 0;
+    int kslice = ktot;
+    if (a.split_k > 1) {
+        if (a.nseg != 1 || !a.out_f32 || a.out_op || a.n_gn || a.bias || a.rowbias || a.residual || a.act)
+            return fail(ADCDIFF_E_BADARG, "gemm: split_k needs one K segment and out_f32 as the only output, no bias / rowbias / residual / act");
+        if (ktot % (a.split_k * bk) != 0 || a.split_stride < (long long)(a.M - 1) * a.ldo_f32 + a.N)
+            return fail(ADCDIFF_E_BADARG, "gemm: split_k=%d must divide K=%d into multiples of %d, split_stride=%lld must hold one output", a.split_k,
+                        ktot, bk, a.split_stride);
+        kslice = ktot / a.split_k;
+        p.ksplit = a.split_k; p.split_k_bytes = (long long)kslice * esize; p.split_out_stride = a.split_stride;
+    }
+    p.W = a.W; p.ldw = a.ldw; p.M = a.M; p.N = a.N; p.nt_total = kslice / bk;
+    if (a.split_k > 1) p.ktiles[0] = kslice / bk;
     p.m_valid = a.m_valid == 0 ? a.M : a.m_valid;
     p.bias = a.bias; p.rowbias = a.rowbias; p.ldrb = a.ldrb; p.rowbias_idx = a.rowbias_idx;
     p.residual = a.residual; p.ldr = a.ldr; p.act = a.act;
@@ -796,12 +814,12 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     bool big = false;
     if (a.dtype == ADCDIFF_BF16 && a.M % 256 == 0 && a.N % 256 == 0 && a.tile_hint != 128) {
         static const int forced = [] { const char* e = getenv("ADCDIFF_GEMM_TILE"); return e ? atoi(e) : 0; }();   // measurement aid
-        const bool enough_tiles = forced != 128 && (long)(a.M / 256) * (a.N / 256) >= 192;
-        const bool long_k = ktot >= 2048 || (nout >= 3.0 * esz && ktot >= 768);
+        const bool enough_tiles = forced != 128 && (long)(a.M / 256) * (a.N / 256) * p.ksplit >= 192;
+        const bool long_k = kslice >= 2048 || (nout >= 3.0 * esz && kslice >= 768);
         big = forced == 256 || a.tile_hint == 256 || (enough_tiles && long_k);
     }
     // few rows (the float32 batch-4096 case, small generation batches): 64 x 64 tiles give four times the workgroups
-    bool small = (long)(a.M / 128) * (a.N / (wide ? 128 : 64)) < 256 && a.tile_hint != 128;
+    bool small = (long)(a.M / 128) * (a.N / (wide ? 128 : 64)) * p.ksplit < 256 && a.tile_hint != 128;
     // only where the GroupNorm groups stay inside a 32-column wave tile: every kernel then sums a group in the same
     // order, so a row's result does not depend on the batch size it is computed in (bit for bit)
     for (int g = 0; g < a.n_gn; ++g) small = small && a.gn[g].group_size <= 32;

@@ -52,73 +52,126 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const InT* __restri
     }
 }
 
-// Backward of a = dropout(SiLU(GroupNorm(u))) for 32 rows x 4 columns per thread:
+// Backward of a = dropout(SiLU(GroupNorm(u))), 4 columns x rpt consecutive rows per thread:
 //   d_u = rstd * (dxh - mean_g(dxh) - xh * mean_g(dxh * xh)),  dxh = dA * keep * silu'(n) * gamma,  n = xh * gamma + beta
 //   dgamma[c] += sum_rows dA * keep * silu'(n) * xh,   dbeta[c] += sum_rows dA * keep * silu'(n)
 // dst = (accumulate ? dst : 0) + d_u + add.
+// A workgroup is c4t = min(C / 4, 256) column lanes x 256 / c4t row lanes (no idle lanes for narrow layers); the host picks
+// rpt (8..32) so that the grid has enough workgroups; rows are taken two at a time so that four loads are in flight.
 __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* __restrict__ u, long ldu, const float* __restrict__ dA, long ldda,
-                                                          int rows, int c4, int lanes_per_group, float inv_gs,
+                                                          int rows, int c4t, int rpt, int lanes_per_group, float inv_gs,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                           float drop_p, uint64_t drop_seed, uint32_t drop_layer, int drop_col0,
                                                           const float* __restrict__ add, long ldadd, float* __restrict__ dst, long lddst,
-                                                          int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    const bool col_live = q < c4;
-    const int col = (col_live ? q : 0) * 4;
+                                                          int accumulate, float* __restrict__ part, long part_stride) {
+    __shared__ float red[2][4 * 256];
+    const int cq = threadIdx.x % c4t, ry = threadIdx.x / c4t, ryc = 256 / c4t;
+    const int col = (blockIdx.x * c4t + cq) * 4;
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
     const f32x4 b = *reinterpret_cast<const f32x4*>(beta + col);
     f32x4 dg = {0, 0, 0, 0}, db = {0, 0, 0, 0};
-    const int rbeg = blockIdx.y * 32;
-    const int rend = rbeg + 32 < rows ? rbeg + 32 : rows;
-    for (int r = rbeg; r < rend; ++r) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(u + (long)r * ldu + col);
-        const f32x4 da = *reinterpret_cast<const f32x4*>(dA + (long)r * ldda + col);
-        float s = (x[0] + x[1]) + (x[2] + x[3]);
-        for (int m = 1; m < lanes_per_group; m <<= 1) s += __shfl_xor(s, m);
-        const float mean = s * inv_gs;
-        const f32x4 d = {x[0] - mean, x[1] - mean, x[2] - mean, x[3] - mean};
-        float v = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
-        for (int m = 1; m < lanes_per_group; m <<= 1) v += __shfl_xor(v, m);
-        const float rstd = 1.0f / __builtin_sqrtf(v * inv_gs + eps);
-        f32x4 keep = {1.0f, 1.0f, 1.0f, 1.0f};
-        if (drop_p > 0.0f) keep = dropout_keep4(drop_seed, drop_layer, (uint64_t)r, (uint32_t)((drop_col0 + col) >> 2), drop_p);
-        f32x4 xh, dxh;
-        float s1 = 0.0f, s2 = 0.0f;
+    const int rbeg = (blockIdx.y * ryc + ry) * rpt;
+    const int rend = rbeg + rpt < rows ? rbeg + rpt : rows;
+    for (int r0 = rbeg; r0 < rend; r0 += 2) {
+        // the second row of the pair repeats the first when the range ends on an odd row; its results are discarded
+        const bool two = r0 + 1 < rend;
+        const int rr[2] = {r0, two ? r0 + 1 : r0};
+        f32x4 xs[2], das[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            xh[i] = d[i] * rstd;
-            const float n = xh[i] * g[i] + b[i];
-            const float sig = 1.0f / (1.0f + expf(-n));
-            const float dn = da[i] * keep[i] * (sig * (1.0f + n * (1.0f - sig)));
-            dg[i] += dn * xh[i];
-            db[i] += dn;
-            dxh[i] = dn * g[i];
-            s1 += dxh[i];
-            s2 += dxh[i] * xh[i];
+        for (int k = 0; k < 2; ++k) {
+            xs[k] = *reinterpret_cast<const f32x4*>(u + (long)rr[k] * ldu + col);
+            das[k] = *reinterpret_cast<const f32x4*>(dA + (long)rr[k] * ldda + col);
         }
-        for (int m = 1; m < lanes_per_group; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
-        s1 *= inv_gs; s2 *= inv_gs;
-        if (col_live) {
-            f32x4 o;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = rstd * (dxh[i] - s1 - xh[i] * s2);
-            if (add) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(add + (long)r * ldadd + col);
+        for (int k = 0; k < 2; ++k) {
+            const int r = rr[k];
+            const f32x4 x = xs[k], da = das[k];
+            float s = (x[0] + x[1]) + (x[2] + x[3]);
+            for (int m = 1; m < lanes_per_group; m <<= 1) s += __shfl_xor(s, m);
+            const float mean = s * inv_gs;
+            const f32x4 d = {x[0] - mean, x[1] - mean, x[2] - mean, x[3] - mean};
+            float v = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            for (int m = 1; m < lanes_per_group; m <<= 1) v += __shfl_xor(v, m);
+            const float rstd = 1.0f / __builtin_sqrtf(v * inv_gs + eps);
+            f32x4 keep = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (drop_p > 0.0f) keep = dropout_keep4(drop_seed, drop_layer, (uint64_t)r, (uint32_t)((drop_col0 + col) >> 2), drop_p);
+            f32x4 xh, dxh;
+            float s1 = 0.0f, s2 = 0.0f;
+            const bool count = k == 0 || two;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] += a[i];
+            for (int i = 0; i < 4; ++i) {
+                xh[i] = d[i] * rstd;
+                const float n = xh[i] * g[i] + b[i];
+                const float sig = 1.0f / (1.0f + expf(-n));
+                const float dn = da[i] * keep[i] * (sig * (1.0f + n * (1.0f - sig)));
+                if (count) { dg[i] += dn * xh[i]; db[i] += dn; }
+                dxh[i] = dn * g[i];
+                s1 += dxh[i];
+                s2 += dxh[i] * xh[i];
             }
-            float* dp = dst + (long)r * lddst + col;
-            if (accumulate) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(dp);
+            for (int m = 1; m < lanes_per_group; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+            s1 *= inv_gs; s2 *= inv_gs;
+            if (count) {
+                f32x4 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] += a[i];
+                for (int i = 0; i < 4; ++i) o[i] = rstd * (dxh[i] - s1 - xh[i] * s2);
+                if (add) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(add + (long)r * ldadd + col);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] += a[i];
+                }
+                float* dp = dst + (long)r * lddst + col;
+                if (accumulate) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(dp);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] += a[i];
+                }
+                *reinterpret_cast<f32x4*>(dp) = o;
             }
-            *reinterpret_cast<f32x4*>(dp) = o;
         }
     }
-    if (col_live) {
+    // d(gamma), d(beta): sum the workgroup's row lanes in LDS (fixed order), then one partial row per workgroup; the column
+    // sums over the partial rows are taken by colsum_partials_kernel -- no atomics (thousands of float atomics on the few
+    // cache lines of a [C] vector serialise in L2 and cost more than the rest of this kernel)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { atomicAdd(dgamma + col + i, dg[i]); atomicAdd(dbeta + col + i, db[i]); }
+    for (int i = 0; i < 4; ++i) { red[0][(ry * c4t + cq) * 4 + i] = dg[i]; red[1][(ry * c4t + cq) * 4 + i] = db[i]; }
+    __syncthreads();
+    if (ry == 0) {
+        f32x4 sg = {0, 0, 0, 0}, sb = {0, 0, 0, 0};
+        for (int y = 0; y < ryc; ++y)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sg[i] += red[0][(y * c4t + cq) * 4 + i]; sb[i] += red[1][(y * c4t + cq) * 4 + i]; }
+        float* pr = part + (long)blockIdx.y * part_stride + col;
+        *reinterpret_cast<f32x4*>(pr) = sg;
+        *reinterpret_cast<f32x4*>(pr + part_stride / 2) = sb;
+    }
+}
+
+// dst0[c] += sum_r part[r * stride + c],  dst1[c] += sum_r part[r * stride + stride / 2 + c]: 64 columns per workgroup
+// (16 lanes x float4), 16 row lanes that each sum every 16th row in index order, combined through LDS in lane order.
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int nrows, long stride, int C, float* __restrict__ dst0,
+                                                              float* __restrict__ dst1) {
+    __shared__ float red[16][64];
+    const int which = blockIdx.y;
+    const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cx * 4;
+    f32x4 s = {0, 0, 0, 0};
+    if (c < C) {
+        const float* src = part + (which ? stride / 2 : 0) + c;
+        for (int r = ly; r < nrows; r += 16) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)r * stride);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[ly][cx * 4 + i] = s[i];
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+        float t = 0.0f;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) t += red[y][threadIdx.x];
+        float* d = which ? dst1 : dst0;
+        d[blockIdx.x * 64 + threadIdx.x] += t;
     }
 }
 
@@ -146,14 +199,17 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__
                                                        float* __restrict__ dpred, long ldd, int rows, int cols, float scale, float* loss) {
     __shared__ float part[4];
     const long n = (long)rows * cols;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
     float sq = 0.0f;
-    if (e < n) {
-        const long r = e / cols;
-        const int c = (int)(e - r * cols);
-        const float d = pred[r * ldp + c] - target[r * ldt_ + c];
-        dpred[r * ldd + c] = 2.0f * scale * d / (float)n;
-        sq = d * d;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {   // 4096 elements per workgroup: one atomic on the loss per 4096 elements
+        const long e = ((long)blockIdx.x * 16 + k) * 256 + threadIdx.x;
+        if (e < n) {
+            const long r = e / cols;
+            const int c = (int)(e - r * cols);
+            const float d = pred[r * ldp + c] - target[r * ldt_ + c];
+            dpred[r * ldd + c] = 2.0f * scale * d / (float)n;
+            sq += d * d;
+        }
     }
     for (int m = 32; m > 0; m >>= 1) sq += __shfl_xor(sq, m);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
@@ -190,13 +246,26 @@ static int transpose_op(const void* src, long lds_, int rows, int rows_pad, int 
 
 static int gn_silu_bwd(const float* u, long ldu, const float* dA, long ldda, int rows, int C, int groups, const float* gamma,
                        const float* beta, float drop_p, uint64_t drop_seed, uint32_t drop_layer, int drop_col0, const float* add,
-                       long ldadd, float* dst, long lddst, int accumulate, float* dgamma, float* dbeta, hipStream_t st) {
+                       long ldadd, float* dst, long lddst, int accumulate, float* dgamma, float* dbeta, Bump& ws, bool dry, hipStream_t st) {
     const int gs = C / groups;
     if (gs < 4 || gs > 256 || (gs & (gs - 1)) != 0)
         return fail(ADCDIFF_E_BADARG, "training needs GroupNorm groups that are powers of two in 4..256 (got %d)", gs);
-    const dim3 grid((unsigned)((C / 4 + 255) / 256), (unsigned)((rows + 31) / 32));
-    hipLaunchKernelGGL(gn_silu_bwd_kernel, grid, dim3(256), 0, st, u, ldu, dA, ldda, rows, C / 4, gs / 4, 1.0f / (float)gs, gamma, beta, 1e-5f,
-                       drop_p, drop_seed, drop_layer, drop_col0, add, ldadd, dst, lddst, accumulate, dgamma, dbeta);
+    const int c4 = C / 4;
+    // column lanes per workgroup: all of them up to 256 (a power of two, so that it divides 256 and holds whole groups)
+    if (C % 4 != 0 || (c4 <= 256 ? (c4 & (c4 - 1)) != 0 : c4 % 256 != 0))
+        return fail(ADCDIFF_E_BADARG, "training needs a channel count that is a power of two up to 1024 or a multiple of 1024 (got %d)", C);
+    const int c4t = c4 < 256 ? c4 : 256, ryc = 256 / c4t;
+    int rpt = 32;
+    while (rpt > 8 && (long)(c4 / c4t) * ((rows + ryc * rpt - 1) / (ryc * rpt)) < 1024) rpt >>= 1;
+    const int nby = (rows + ryc * rpt - 1) / (ryc * rpt);
+    const size_t keep = ws.off;
+    float* part = (float*)ws.take((size_t)nby * 2 * C * 4);   // one (d gamma | d beta) row per workgroup row; dead after the column sums
+    ws.off = keep;
+    if (dry) return ADCDIFF_OK;
+    const dim3 grid((unsigned)(c4 / c4t), (unsigned)nby);
+    hipLaunchKernelGGL(gn_silu_bwd_kernel, grid, dim3(256), 0, st, u, ldu, dA, ldda, rows, c4t, rpt, gs / 4, 1.0f / (float)gs, gamma, beta, 1e-5f,
+                       drop_p, drop_seed, drop_layer, drop_col0, add, ldadd, dst, lddst, accumulate, part, (long)2 * C);
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)((C + 63) / 64), 2), dim3(256), 0, st, part, nby, (long)2 * C, C, dgamma, dbeta);
     return check_launch("gn_silu_bwd");
 }
 
@@ -205,6 +274,48 @@ static int gemm_simple(int dt, const void* A, int lda, const void* W, int ldw, i
     adcdiff_gemm_args g = gemm_args(dt, M, m_valid, N);
     g.nseg = 1; g.A[0] = A; g.lda[0] = lda; g.K[0] = K; g.W = W; g.ldw = ldw; g.out_f32 = out; g.ldo_f32 = ldo;
     return gemm_dispatch(g, st);
+}
+
+// dst[e] = sum over s of part[s * stride + e], slices in index order (n % 4 == 0, 16-byte aligned)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int slices, long stride, long n4, float* __restrict__ dst) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n4) return;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(part + q * 4);
+    for (int s = 1; s < slices; ++s) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(part + (long)s * stride + q * 4);
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    *reinterpret_cast<f32x4*>(dst + q * 4) = acc;
+}
+
+// K slices for a weight-gradient GEMM out[M, N] = A[M, K] W[N, K]^T whose K is the batch: enough that slices x tiles fill
+// the chip, each slice at least 512 long.  Depends on the shapes only, so the sizing dry run takes the same decision.
+static int dw_slices(int M, int N, int K) {
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    int s = 1;
+    while (tiles * s < 256 && K % (s * 2 * 128) == 0 && K / (s * 2) >= 512) s *= 2;
+    return s;
+}
+
+// d(weight)[M, N] = A[M, K] W[N, K]^T (both operands K-major), split over K when M x N alone leaves most CUs idle: the
+// slices' partial products go to the workspace and are summed in slice order (deterministic, unlike atomics).
+static int gemm_dw(int dt, const void* A, const void* W, int M, int N, int K, float* out, Bump& ws, bool dry, hipStream_t st) {
+    const int slices = dw_slices(M, N, K);
+    if (slices == 1) {
+        if (dry) return ADCDIFF_OK;
+        return gemm_simple(dt, A, K, W, K, M, 0, N, K, out, N, st);
+    }
+    const size_t keep = ws.off;
+    float* part = (float*)ws.take((size_t)slices * M * N * 4);
+    ws.off = keep;   // the partials are dead once summed; the next take may reuse them (the peak is recorded)
+    if (dry) return ADCDIFF_OK;
+    adcdiff_gemm_args g = gemm_args(dt, M, 0, N);
+    g.nseg = 1; g.A[0] = A; g.lda[0] = K; g.K[0] = K; g.W = W; g.ldw = K; g.out_f32 = part; g.ldo_f32 = N;
+    g.split_k = slices; g.split_stride = (long long)M * N;
+    TRY(gemm_dispatch(g, st));
+    const long n4 = (long)M * N / 4;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, slices, (long)M * N, n4, out);
+    return check_launch("sum_partials");
 }
 
 static int copy_f32(const float* src, float* dst, long n, int accumulate, hipStream_t st) {
@@ -260,7 +371,7 @@ extern "C" int adcdiff_mse_loss_grad(const float* pred, int ldp, const float* ta
     if (!pred || !target || !dpred || !loss_accum || B <= 0 || D <= 0 || ldp < D || ldt < D || ldd < D)
         return fail(ADCDIFF_E_BADARG, "mse_loss_grad: bad arguments");
     const long nel = (long)B * D;
-    hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, as_stream(stream_), pred, (long)ldp, target, (long)ldt,
+    hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)((nel + 4095) / 4096)), dim3(256), 0, as_stream(stream_), pred, (long)ldp, target, (long)ldt,
                        dpred, (long)ldd, B, D, scale, loss_accum);
     return check_launch("mse_loss_grad");
 }
@@ -314,13 +425,13 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         RUN(cast_transpose<float>(d_eps, lde, B, Bp, O, dt, dE_rm, O, dE_t, Bp, gr->out_b, st));
         void* aT = ws.take((size_t)H * Bp * e);
         RUN(transpose_op(tp.a_out, H, B, Bp, H, dt, aT, st));
-        RUN(gemm_simple(dt, dE_t, Bp, aT, Bp, O, 0, H, Bp, gr->out_w, H, st));
+        TRY(gemm_dw(dt, dE_t, aT, O, H, Bp, gr->out_w, ws, dry, st));
         void* wT = ws.take((size_t)H * O * e);
         RUN(cast_transpose<float>(p.out_w, H, O, O, H, dt, nullptr, 0, wT, O, nullptr, st));
         float* d_a = (float*)ws.take((size_t)Bp * H * 4);
         RUN(gemm_simple(dt, dE_rm, O, wT, O, Bp, B, H, O, d_a, H, st));
-        RUN(gn_silu_bwd(tp.blk[9].o, n->blk[9].cout, d_a, H, B, H, num_groups(H), p.out_norm_w, p.out_norm_b, 0.0f, 0, 0, 0, nullptr, 0, dO[9],
-                        n->blk[9].cout, 0, gr->out_norm_w, gr->out_norm_b, st));
+        TRY(gn_silu_bwd(tp.blk[9].o, n->blk[9].cout, d_a, H, B, H, num_groups(H), p.out_norm_w, p.out_norm_b, 0.0f, 0, 0, 0, nullptr, 0, dO[9],
+                        n->blk[9].cout, 0, gr->out_norm_w, gr->out_norm_b, ws, dry, st));
         dO_written[9] = true;
     }
     const size_t mark = ws.off;
@@ -340,7 +451,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         // (2) d(linear2.weight) = dO^T a2
         void* xT = ws.take((size_t)(cin > cout ? cin : cout) * Bp * e);
         RUN(transpose_op(bt.a2, cout, B, Bp, cout, dt, xT, st));
-        RUN(gemm_simple(dt, dO_t, Bp, xT, Bp, cout, 0, cout, Bp, g.linear2_w, cout, st));
+        TRY(gemm_dw(dt, dO_t, xT, cout, cout, Bp, g.linear2_w, ws, dry, st));
         // (3) residual_proj: d(weight) = dO^T x, d(x) = dO Wres
         float* d_raw = nullptr;
         void* wT = ws.take((size_t)(cin > cout ? cin : cout) * cout * e);
@@ -350,7 +461,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
                 RUN(transpose_op(bt.in_raw[k], b.part_c[k], B, Bp, b.part_c[k], dt, (char*)xT + (size_t)row0 * Bp * e, st));
                 row0 += b.part_c[k];
             }
-            RUN(gemm_simple(dt, dO_t, Bp, xT, Bp, cout, 0, cin, Bp, g.residual_w, cin, st));
+            TRY(gemm_dw(dt, dO_t, xT, cout, cin, Bp, g.residual_w, ws, dry, st));
             RUN(cast_transpose<float>(q.residual_w, cin, cout, cout, cin, dt, nullptr, 0, wT, cout, nullptr, st));
             d_raw = (float*)ws.take((size_t)Bp * cin * 4);
             RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cin, cout, d_raw, cin, st));
@@ -360,8 +471,8 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         float* d_a2 = (float*)ws.take((size_t)Bp * cout * 4);
         RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cout, cout, d_a2, cout, st));
         float* d_h1 = (float*)ws.take((size_t)Bp * cout * 4);
-        RUN(gn_silu_bwd(bt.h1, cout, d_a2, cout, B, cout, b.g2, q.norm2_w, q.norm2_b, tp.drop_p, tp.drop_seed, (uint32_t)i, 0, nullptr, 0, d_h1,
-                        cout, 0, g.norm2_w, g.norm2_b, st));
+        TRY(gn_silu_bwd(bt.h1, cout, d_a2, cout, B, cout, b.g2, q.norm2_w, q.norm2_b, tp.drop_p, tp.drop_seed, (uint32_t)i, 0, nullptr, 0, d_h1,
+                        cout, 0, g.norm2_w, g.norm2_b, ws, dry, st));
         // (6) d(h1): column sums are d(linear1.bias) = d(time_proj.bias); (7) rows go to the timestep table
         RUN(cast_transpose<float>(d_h1, cout, B, Bp, cout, dt, dO_rm, cout, dO_t, Bp, g.linear1_b, st));
         RUN(copy_f32(g.linear1_b, g.time_proj_b, cout, 0, st));
@@ -375,7 +486,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         }
         // (8) d(linear1.weight) = d_h1^T a1; (9) d(a1) = d_h1 W1
         RUN(transpose_op(bt.a1, cin, B, Bp, cin, dt, xT, st));
-        RUN(gemm_simple(dt, dO_t, Bp, xT, Bp, cout, 0, cin, Bp, g.linear1_w, cin, st));
+        TRY(gemm_dw(dt, dO_t, xT, cout, cin, Bp, g.linear1_w, ws, dry, st));
         RUN(cast_transpose<float>(q.linear1_w, cin, cout, cout, cin, dt, nullptr, 0, wT, cout, nullptr, st));
         float* d_a1 = (float*)ws.take((size_t)Bp * cin * 4);
         RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cin, cout, d_a1, cin, st));
@@ -390,8 +501,8 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             const int acc = src >= 0 && dO_written[src] ? 1 : 0;
             const float* add = b.has_res ? d_raw + col : dO[i];     // Identity residual passes dO straight through
             const long ldadd = b.has_res ? cin : cout;
-            RUN(gn_silu_bwd(bt.in_f32[k], bt.in_ld[k], d_a1 + col, cin, B, b.part_c[k], b.part_c[k] / b.gs1, q.norm1_w + col, q.norm1_b + col, 0.0f,
-                            0, 0, 0, add, ldadd, dst, lddst, acc, g.norm1_w + col, g.norm1_b + col, st));
+            TRY(gn_silu_bwd(bt.in_f32[k], bt.in_ld[k], d_a1 + col, cin, B, b.part_c[k], b.part_c[k] / b.gs1, q.norm1_w + col, q.norm1_b + col, 0.0f,
+                            0, 0, 0, add, ldadd, dst, lddst, acc, g.norm1_w + col, g.norm1_b + col, ws, dry, st));
             if (src >= 0) dO_written[src] = true;
             col += b.part_c[k];
         }

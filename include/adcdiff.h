@@ -90,6 +90,12 @@ typedef struct adcdiff_gemm_args {
     adcdiff_gn_out gn[2];
     float gn_eps;
     int tile_hint;             /* 0 = choose; 128 / 256 = force that tile kernel where the shape allows (A/B measurements, tests) */
+    int split_k;               /* 0 / 1 = off.  S > 1: the K dimension (one segment, a multiple of S * 64 bf16 / S * 32 f32) is cut
+                                  into S equal slices computed by separate workgroups; slice s writes its partial product to
+                                  out_f32 + s * split_stride and the caller sums the S partials in a fixed order.  For
+                                  weight-gradient GEMMs (K = batch) whose M x N gives too few tiles to fill the chip.  Only with
+                                  out_f32 as the sole output and no bias / rowbias / residual / act. */
+    long long split_stride;    /* floats between consecutive partial outputs */
 } adcdiff_gemm_args;
 int adcdiff_gemm(const adcdiff_gemm_args* args, adcdiff_stream_t stream);
 
