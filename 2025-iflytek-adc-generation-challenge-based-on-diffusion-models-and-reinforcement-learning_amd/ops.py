@@ -47,11 +47,13 @@ def _operand(x, code):
 
 
 def gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, act=0, out_f32=True, out_op=False, gn=(),
-         m_valid=None, dtype="fp32", eps=1e-5, tile_hint=0):
+         m_valid=None, dtype="fp32", eps=1e-5, tile_hint=0, split_k=0):
     """adcdiff_gemm: v = [A0|A1|A2] @ w.T + bias + rowbias + residual.
 
     a_list: operand tensors [M, K_s] (M a multiple of 128) already in the operand dtype; w [N, sum K_s]; residual in the
     operand dtype; gn: up to two (gamma, beta, group_size) for fused SiLU(GroupNorm(v)) outputs in the operand dtype.
+    split_k = S > 1: K is cut into S slices computed by separate workgroups; the float32 result then has shape [S, M, N]
+    (the slices' partial products, to be summed by the caller).
     Returns the requested outputs in the order (v float32, v operand type, gn outputs...), a single tensor if only one."""
     lib = _lib.load()
     code = dtype_code(dtype)
@@ -76,8 +78,9 @@ def gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, ac
     args.tile_hint = tile_hint
     outs = []
     if out_f32:
-        o = torch.empty((M, N), device=w.device, dtype=torch.float32)
+        o = torch.empty((split_k, M, N) if split_k > 1 else (M, N), device=w.device, dtype=torch.float32)
         args.out_f32, args.ldo_f32 = o.data_ptr(), N
+        args.split_k, args.split_stride = int(split_k), M * N
         outs.append(o)
     if out_op:
         o = torch.empty((M, N), device=w.device, dtype=td)

@@ -231,3 +231,26 @@ def test_latent_summary_is_numpy_bit_for_bit(D):
 def test_latent_summary_rejects_unsupported_width():
     with pytest.raises(Exception, match="128"):
         ops.latent_summary(torch.zeros(4, 320, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 2e-5)])
+@pytest.mark.parametrize("M,N,K,S", [(128, 64, 2048, 4), (256, 512, 4096, 8), (512, 256, 32768, 32)])
+def test_split_k_partials_sum_to_the_unsplit_product(dtype, tol, M, N, K, S):
+    """split_k: the S partial products of the K slices, summed, equal the unsplit GEMM on the same (already rounded)
+    operands up to float32 summation order (2e-5 of the largest entry: sqrt(K) roundings of 6e-8); each partial equals the GEMM of its slice bit for
+    bit.  Shapes of the weight-gradient GEMMs (M x N small, K = batch)."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    gen = torch.Generator(device="cpu").manual_seed(K + S)
+    a = torch.randn(M, K, generator=gen).cuda().to(td)
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).cuda().to(td)
+    full = ops.gemm([a], w, dtype=dtype)
+    parts = ops.gemm([a], w, dtype=dtype, split_k=S)
+    assert parts.shape == (S, M, N)
+    scale = float(full.abs().max())
+    assert float((parts.sum(0) - full).abs().max()) <= tol * scale
+    ks = K // S
+    for s_ in (0, S - 1):
+        one = ops.gemm([a[:, s_ * ks:(s_ + 1) * ks]], w[:, s_ * ks:(s_ + 1) * ks], dtype=dtype)
+        assert torch.equal(one, parts[s_])
+    with pytest.raises(Exception, match="split_k"):
+        ops.gemm([a], w, dtype=dtype, split_k=S, bias=torch.zeros(N, device="cuda"))
