@@ -68,6 +68,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
+// The same copy issued from inline asm: hipcc does not track it, so it inserts no vmcnt(0) in front of the next ds_read
+// (which it does for the builtin whenever the destination may alias) and a prefetch really stays in flight under the
+// MFMAs; the loops that use it count vmcnt by hand.  M0 carries the wave-uniform LDS byte address and is restored.
+__device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
 template <typename T>
 __device__ __forceinline__ float silu_out(float v) {
     if constexpr (sizeof(T) == 2) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));   // result is rounded to bf16
@@ -353,20 +364,43 @@ struct Epilogue {
     }
 };
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `tiles` (wave-uniform, 0..7) groups of P vector-memory operations are outstanding
+template <int P>
+__device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
+    switch (tiles) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<P>(); break;
+        case 2: wait_vmcnt<2 * P>(); break;
+        case 3: wait_vmcnt<3 * P>(); break;
+        case 4: wait_vmcnt<(4 * P <= 63 ? 4 * P : 63)>(); break;
+        case 5: wait_vmcnt<(5 * P <= 63 ? 5 * P : 63)>(); break;
+        case 6: wait_vmcnt<(6 * P <= 63 ? 6 * P : 63)>(); break;
+        default: wait_vmcnt<(7 * P <= 63 ? 7 * P : 63)>(); break;
+    }
+}
+
+// NSTAGE = 1: the structure described at the top (one stage, latency hidden by the other resident workgroups).
+// NSTAGE > 1: a ring of NSTAGE stages with the LDS-DMA of K tile t + NSTAGE - 1 issued right after the barrier of tile t, one
+// barrier per tile -- for launches with so few workgroups (small batches, the float32 batch-4096 case) that nothing else on
+// the CU hides the load latency of a tile (~1 us per K tile otherwise); one such workgroup per CU, so LDS is plentiful.
+template <typename T, int BM, int BN, int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void gemm_nt_kernel(const GemmParams p) {
     constexpr bool BF = sizeof(T) == 2;
     constexpr int A_BYTES = BM * 128;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
     constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile (2 x 2 waves)
     constexpr int TS = BF ? 16 : 32;           // MFMA tile edge: 16x16x32 bf16 / 32x32x2 f32
     constexpr int TM = WTM / TS, TN = WTN / TS;
     constexpr int NACC = BF ? 4 : 16;
     constexpr int A_PIECES = BM / 8 / 4, B_PIECES = BN / 8 / 4;   // 1 KiB pieces (8 rows) per wave
     typedef Epilogue<T, 256, BN, WTM, WTN, TM, TN> Epi;
-    constexpr int MAIN_BYTES = (BM + BN) * 128 > Epi::STAGE_BYTES ? (BM + BN) * 128 : Epi::STAGE_BYTES;
+    constexpr int MAIN_BYTES = NSTAGE * STAGE_BYTES > Epi::STAGE_BYTES ? NSTAGE * STAGE_BYTES : Epi::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sa = smem;
-    char* const sb = smem + A_BYTES;
     float* const prm = reinterpret_cast<float*>(smem + MAIN_BYTES);
     float* const xch = prm + 5 * BN;
 
@@ -415,25 +449,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
     const int frow = BF ? (lane & 15) : (lane & 31);
     const int fchunk = BF ? (lane >> 4) : (lane >> 5);
 
-    int seg = 0, tt = 0;
-    const char* Ab = reinterpret_cast<const char*>(p.A[0]) + ksb;
-    long lda_b = (long)p.lda[0] * (long)sizeof(T);
-    for (int t = 0; t < p.nt_total; ++t, ++tt) {
-        if (tt == p.ktiles[seg]) {   // next K segment (wave-uniform)
-            ++seg; tt = 0;
-            if (tt == p.ktiles[seg]) { ++seg; }
-            Ab = reinterpret_cast<const char*>(seg == 1 ? p.A[1] : p.A[2]);
-            lda_b = (long)(seg == 1 ? p.lda[1] : p.lda[2]) * (long)sizeof(T);
-        }
-        const long ka = (long)tt * 128, kw = (long)t * 128;
-#pragma unroll
-        for (int j = 0; j < A_PIECES; ++j)
-            glds16(Ab + (long)a_row[j] * lda_b + ka + a_off[j], sa + (wave * A_PIECES + j) * 1024);
-#pragma unroll
-        for (int j = 0; j < B_PIECES; ++j)
-            glds16(Wb + b_off[j] + kw, sb + (wave * B_PIECES + j) * 1024);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    // the MFMAs of one K tile staged at sa (A rows) / sb (W rows)
+    auto compute = [&](const char* sa, const char* sb) {
         if constexpr (BF) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -480,6 +497,69 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
             }
         }
+    };
+
+    int seg = 0, tt = 0;     // load cursor over the K segments
+    const char* Ab = reinterpret_cast<const char*>(p.A[0]) + ksb;
+    long lda_b = (long)p.lda[0] * (long)sizeof(T);
+    if constexpr (NSTAGE == 1) {
+        char* const sa = smem;
+        char* const sb = smem + A_BYTES;
+        for (int t = 0; t < p.nt_total; ++t, ++tt) {
+            if (tt == p.ktiles[seg]) {   // next K segment (wave-uniform)
+                ++seg; tt = 0;
+                if (tt == p.ktiles[seg]) { ++seg; }
+                Ab = reinterpret_cast<const char*>(seg == 1 ? p.A[1] : p.A[2]);
+                lda_b = (long)(seg == 1 ? p.lda[1] : p.lda[2]) * (long)sizeof(T);
+            }
+            const long ka = (long)tt * 128, kw = (long)t * 128;
+#pragma unroll
+            for (int j = 0; j < A_PIECES; ++j)
+                glds16(Ab + (long)a_row[j] * lda_b + ka + a_off[j], sa + (wave * A_PIECES + j) * 1024);
+#pragma unroll
+            for (int j = 0; j < B_PIECES; ++j)
+                glds16(Wb + b_off[j] + kw, sb + (wave * B_PIECES + j) * 1024);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(sa, sb);
+            __syncthreads();
+        }
+    } else {
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+        const int nt = p.nt_total;
+        int it = 0;          // tiles issued so far
+        auto issue = [&](int slot) {
+            if (tt == p.ktiles[seg]) {
+                ++seg; tt = 0;
+                if (tt == p.ktiles[seg]) { ++seg; }
+                Ab = reinterpret_cast<const char*>(seg == 1 ? p.A[1] : p.A[2]);
+                lda_b = (long)(seg == 1 ? p.lda[1] : p.lda[2]) * (long)sizeof(T);
+            }
+            const long ka = (long)tt * 128, kw = (long)it * 128;
+            const unsigned base = lds0 + slot * STAGE_BYTES;
+#pragma unroll
+            for (int j = 0; j < A_PIECES; ++j) glds16_untracked(Ab + (long)a_row[j] * lda_b + ka + a_off[j], base + (wave * A_PIECES + j) * 1024);
+#pragma unroll
+            for (int j = 0; j < B_PIECES; ++j) glds16_untracked(Wb + b_off[j] + kw, base + A_BYTES + (wave * B_PIECES + j) * 1024);
+            ++tt; ++it;
+        };
+        constexpr int AHEAD = NSTAGE - 1, P = A_PIECES + B_PIECES;
+        static_assert((AHEAD - 1) * P <= 63 && AHEAD <= 8, "prefetch depth exceeds the vmcnt counter");
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k)
+            if (k < nt) issue(k);
+        int slot = 0, free_slot = AHEAD;   // free_slot: the slot of tile t-1 (initially the one the prologue left empty)
+        for (int t = 0; t < nt; ++t) {
+            // this wave's pieces of tile t have landed (up to AHEAD - 1 later tiles may stay in flight) ...
+            const int later = nt - 1 - t;
+            wait_tiles_in_flight<P>(later < AHEAD - 1 ? later : AHEAD - 1);
+            // ... and after the barrier everyone's have, and nobody still reads tile t-1, whose slot takes tile t + AHEAD
+            __builtin_amdgcn_s_barrier();
+            if (t + AHEAD < nt) issue(free_slot);
+            compute(smem + slot * STAGE_BYTES, smem + slot * STAGE_BYTES + A_BYTES);
+            free_slot = slot;
+            slot = slot == NSTAGE - 1 ? 0 : slot + 1;
+        }
         __syncthreads();
     }
 
@@ -487,17 +567,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(const GemmParams p) {
 }
 
 // ---- 256 x 256 tile, 8 waves (2 x 4, 128 x 64 per wave), bf16, one workgroup (2 waves per SIMD) per CU ----------
-// For the large layers (M, N multiples of 256).  Two 64 KiB LDS stages.
-// LDS-DMA issued from inline asm: hipcc does not track it, so it inserts no vmcnt(0) in front of the next ds_read
-// (which it does for the builtin whenever the destination may alias) and the prefetch really stays in flight
-// under the MFMAs; the loop counts vmcnt by hand.  M0 carries the wave-uniform LDS byte address and is restored.
-__device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_addr)
-                 : "memory");
-}
+// For the large layers (M, N multiples of 256).  Two 64 KiB LDS stages; LDS-DMA through glds16_untracked, vmcnt counted by hand.
 
 // Phased main loop: two wave groups half a phase apart.
 // A K tile (64) is four phases of 16 MFMAs per wave, one 64 x 32 quadrant of the wave's 128 x 64 tile each, in the
@@ -720,15 +790,15 @@ static int launch256(const GemmParams& p, hipStream_t stream) {
     return check_launch("gemm256");
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NSTAGE>
 static int launch(const GemmParams& p, hipStream_t stream) {
     constexpr int TS = sizeof(T) == 2 ? 16 : 32;
     typedef Epilogue<T, 256, BN, BM / 2, BN / 2, BM / 2 / TS, BN / 2 / TS> Epi;
-    constexpr int main_bytes = (BM + BN) * 128;
+    constexpr int main_bytes = NSTAGE * (BM + BN) * 128;
     constexpr int smem = (main_bytes > Epi::STAGE_BYTES ? main_bytes : Epi::STAGE_BYTES) + Epi::EXTRA_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN, NSTAGE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -736,8 +806,15 @@ static int launch(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     q.ntn = p.N / BN;
     const int grid = (p.M / BM) * q.ntn;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN>), dim3(grid, p.ksplit), dim3(256), smem, stream, q);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, NSTAGE>), dim3(grid, p.ksplit), dim3(256), smem, stream, q);
     return check_launch("gemm");
+}
+
+template <typename T, int BM, int BN>
+static int launch_any(const GemmParams& p, bool ring, hipStream_t stream) {
+    // three stages: deeper rings (six stages of 64 x 64, four of 128 x 128) measured 3-5 % slower -- past a prefetch distance
+    // of two tiles the per-tile barrier and LDS-DMA issue are the critical path, not the load latency
+    return ring ? launch<T, BM, BN, 3>(p, stream) : launch<T, BM, BN, 1>(p, stream);
 }
 
 int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
@@ -819,7 +896,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         big = forced == 256 || a.tile_hint == 256 || (enough_tiles && long_k);
     }
     // few rows (the float32 batch-4096 case, small generation batches): 64 x 64 tiles give four times the workgroups
-    bool small = (long)(a.M / 128) * (a.N / (wide ? 128 : 64)) * p.ksplit < 256 && a.tile_hint != 128;
+    bool small = (long)(a.M / 128) * (a.N / (wide ? 128 : 64)) * p.ksplit < 256 && a.tile_hint != 128 && a.tile_hint != 1 && a.tile_hint != 3;
     // only where the GroupNorm groups stay inside a 32-column wave tile: every kernel then sums a group in the same
     // order, so a row's result does not depend on the batch size it is computed in (bit for bit)
     for (int g = 0; g < a.n_gn; ++g) small = small && a.gn[g].group_size <= 32;
@@ -827,12 +904,16 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     TimingScope ts(kind, a.M, a.N, ktot, 2.0 * a.M * a.N * ktot,
                    esz * ((double)a.M * ktot + (double)a.N * ktot) + (double)a.M * a.N * (nout + (a.residual ? esz : 0.0)), stream);
     if (big) return launch256(p, stream);
+    // few workgroups: nothing else on the CU hides a tile's load latency, so take the three-stage ring
+    const int bn = small ? 64 : wide ? 128 : 64, bm = small ? 64 : 128;
+    const long blocks = (long)(a.M / bm) * (a.N / bn) * p.ksplit;
+    const bool ring = a.tile_hint == 3 || (a.tile_hint != 1 && blocks <= 512);
     if (a.dtype == ADCDIFF_BF16) {
-        if (small) return launch<bf16_t, 64, 64>(p, stream);
-        return wide ? launch<bf16_t, 128, 128>(p, stream) : launch<bf16_t, 128, 64>(p, stream);
+        if (small) return launch_any<bf16_t, 64, 64>(p, ring, stream);
+        return wide ? launch_any<bf16_t, 128, 128>(p, ring, stream) : launch_any<bf16_t, 128, 64>(p, ring, stream);
     }
-    if (small) return launch<float, 64, 64>(p, stream);
-    return wide ? launch<float, 128, 128>(p, stream) : launch<float, 128, 64>(p, stream);
+    if (small) return launch_any<float, 64, 64>(p, ring, stream);
+    return wide ? launch_any<float, 128, 128>(p, ring, stream) : launch_any<float, 128, 64>(p, ring, stream);
 }
 
 }  // namespace adcdiff

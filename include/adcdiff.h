@@ -89,7 +89,8 @@ typedef struct adcdiff_gemm_args {
     int n_gn;                  /* 0..2 fused SiLU(GroupNorm(v)) outputs */
     adcdiff_gn_out gn[2];
     float gn_eps;
-    int tile_hint;             /* 0 = choose; 128 / 256 = force that tile kernel where the shape allows (A/B measurements, tests) */
+    int tile_hint;             /* 0 = choose; 128 / 256 = force that tile kernel where the shape allows; 1 / 3 = force the 128-row kernel
+                                  with one LDS stage / the three-stage ring (A/B measurements, tests) */
     int split_k;               /* 0 / 1 = off.  S > 1: the K dimension (one segment, a multiple of S * 64 bf16 / S * 32 f32) is cut
                                   into S equal slices computed by separate workgroups; slice s writes its partial product to
                                   out_f32 + s * split_stride and the caller sums the S partials in a fixed order.  For
