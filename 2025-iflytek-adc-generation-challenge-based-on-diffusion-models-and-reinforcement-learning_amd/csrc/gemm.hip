@@ -907,7 +907,8 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     // few workgroups: nothing else on the CU hides a tile's load latency, so take the three-stage ring
     const int bn = small ? 64 : wide ? 128 : 64, bm = small ? 64 : 128;
     const long blocks = (long)(a.M / bm) * (a.N / bn) * p.ksplit;
-    const bool ring = a.tile_hint == 3 || (a.tile_hint != 1 && blocks <= 512);
+    static const long ring_max = [] { const char* e = getenv("ADCDIFF_GEMM_RING_MAX"); return e ? atol(e) : 512L; }();   // measurement aid
+    const bool ring = a.tile_hint == 3 || (a.tile_hint != 1 && blocks <= ring_max);
     if (a.dtype == ADCDIFF_BF16) {
         if (small) return launch_any<bf16_t, 64, 64>(p, ring, stream);
         return wide ? launch_any<bf16_t, 128, 128>(p, ring, stream) : launch_any<bf16_t, 128, 64>(p, ring, stream);
