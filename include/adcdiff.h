@@ -285,7 +285,9 @@ int adcdiff_clip_adamw_step(const adcdiff_opt_tensor* tensors, int n_tensors, lo
  * adcdiff_timing_end every GEMM, GroupNorm+SiLU and schedule-update launch made through this library is
  * bracketed by a pair of hipEvents on the stream it is launched on (up to max_records launches; later
  * ones are not recorded).  adcdiff_timing_end synchronises those events and returns one record per
- * launch.  Not thread safe; not for use under graph capture. */
+ * launch; ms is the event-pair time minus the median time of nine empty event pairs recorded on the same
+ * stream at the end (what the two events cost by themselves, ~10-30 us).  Not thread safe; not for use under
+ * graph capture. */
 enum { ADCDIFF_KIND_GEMM_F32 = 0, ADCDIFF_KIND_GEMM_BF16 = 1, ADCDIFF_KIND_GROUPNORM = 2, ADCDIFF_KIND_UPDATE = 3,
        ADCDIFF_KIND_GEMM_BF16_T256 = 4 /* bf16 GEMM that ran on the 256 x 256-tile kernel */ };
 typedef struct adcdiff_timing_record {
