@@ -137,6 +137,25 @@ def test_batch_4096_rows_are_independent_and_shardable(golden_a):
     assert rel_err(full[:32][:, g["fwd.cols"]], g["loop_T1000.values"]) < LOOP_TOL["fp32"]
 
 
+def test_batch_65536_bf16_rows_are_independent_of_the_tiling(golden_a):
+    """Config 3 (bf16 operands, batch 65536 -- the 256 x 256-tile kernel with its phased main loop): rows of the big batch
+    equal the same rows sampled in a batch of 256 (128-row kernel, three-stage ring) and of 77 (64-row tiles), bit for bit,
+    with and without a condition; so the probes that pin the small batches pin the benchmark's batch."""
+    m, _ = build((512, 256, 512), "bf16")
+    steps = dict(t_start=999, t_stop=995)
+    B = 65536
+    big = m.p_sample_loop((B, 512), seed=SEED, **steps)
+    assert torch.isfinite(big).all()
+    for first, count in ((0, 256), (40000, 256), (65459, 77)):
+        part = m.p_sample_loop((count, 512), seed=SEED, row_offset=first, **steps)
+        assert torch.equal(part, big[first:first + count]), (first, count)
+    cond = cu(philox.normal(SEED, 51, 0, 0, 1, 512)).expand(B, -1).contiguous()
+    bigc = m.p_sample_loop((B, 512), condition=cond, seed=SEED, **steps)
+    partc = m.p_sample_loop((256, 512), condition=cond[:256], seed=SEED, row_offset=1024, **steps)
+    assert torch.equal(partc, bigc[1024:1280])
+    assert not torch.equal(bigc[:256], big[:256])
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_unfused_path_for_non_power_of_two_groups(dtype):
     """hidden_dim 192 gives GroupNorm groups of 6, 12, ... channels, which the GEMM epilogue does not take;
