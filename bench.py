@@ -37,18 +37,24 @@ PEAK_HBM_GBS = 8000.0
 SEED = 2025
 
 
-def synthetic_weights():
-    """Counter-hash weights (xavier-uniform range, non-zero biases): integer arithmetic only, so every
-    rank and every machine builds the same tensors without a checkpoint."""
-    from oracle.weights import make_weights
-    return make_weights(1234, *DIMS)
-
-
-def build_model(dtype, weights):
+def build_model(dtype, device):
+    """The denoiser at emb 512 / hidden 256 with synthetic weights drawn on the device from the library's counter RNG
+    (stream 100 + parameter index, so every rank builds the same tensors without a checkpoint): Linear weights
+    N(0, 2 / (fan_in + fan_out)) -- the variance of the reference's xavier_uniform_ init --, biases N(0, 0.05^2), GroupNorm
+    weight 1 + N(0, 0.1^2)."""
     cfg = dict(input_dim=DIMS[0], hidden_dim=DIMS[1], output_dim=DIMS[2], num_timesteps=1000, beta_start=1e-4, beta_end=2e-2,
                compute_dtype=dtype, memory_monitor_enabled=False)
     model = adcdiff.DiffusionModel(cfg)
-    model.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in weights.items()})
+    with torch.no_grad():
+        for i, (name, p) in enumerate(model.model.named_parameters()):
+            n = p.numel()
+            z = ops.philox_normal(1, (n + 3) // 4 * 4, 1234, 100 + i, 0, device=device).reshape(-1)[:n].view_as(p)
+            if p.dim() == 2:
+                p.copy_(z * (2.0 / (p.shape[0] + p.shape[1])) ** 0.5)
+            elif ".norm" in name and name.endswith("weight") or name == "output_norm.weight":
+                p.copy_(1.0 + 0.1 * z)
+            else:
+                p.copy_(0.05 * z)
     return model
 
 
@@ -179,8 +185,7 @@ def main():
     dtype, batch, config_name = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
-    weights = synthetic_weights()
-    model = build_model(dtype, weights)
+    model = build_model(dtype, dev)
     T = args.timesteps
     gathered = torch.empty((world * batch, DIMS[2]), device=dev, dtype=torch.float32) if world > 1 else None
 
@@ -218,12 +223,12 @@ def main():
             "config": {"workload": config_name, "denoiser": "emb 512 / hidden 256 / 44.3M params", "per_gpu_batch": batch,
                        "global_batch": world * batch, "timesteps": T, "sampler": "p_sample_loop (DDPM, linear beta 1e-4..2e-2)",
                        "parallelism": "rows sharded over %d GPU(s), RCCL all-gather of latents" % world,
-                       "weights": "random (counter hash, xavier range), no checkpoint ships"},
+                       "weights": "random (counter RNG, xavier variance), no checkpoint ships"},
             "roofline": main_roof, "roofline_all_gemms": all_roof, "roofline_schedule_update": upd_roof, "groupnorm_kernel": gn_roof,
             "ms_per_denoise_step": round(elapsed / args.steps / T * 1e3, 4), "outputs_finite": finite,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(weights)
+            line["cpu_baseline"] = cpu_baseline({k: v.detach().cpu().numpy() for k, v in model.model.state_dict().items()})
             line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
