@@ -193,6 +193,47 @@ struct Epilogue {
         } else {
             constexpr int IN_WAVE = GS <= WTN ? GS : WTN;   // channels of the group inside this wave
             constexpr int LANES = IN_WAVE / 8;
+            if constexpr (BF) {
+                // bf16 outputs: the same two-pass statistics on pairs of elements (v_pk_add / v_pk_mul / v_pk_fma_f32 do two
+                // lanes' worth per issue slot: the epilogue is VALU-issue bound, ~15 -> ~9 instructions per element), SiLU
+                // through v_exp_f32 / v_rcp_f32 directly
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 d2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d2[i] = f32x2{v[2 * i], v[2 * i + 1]};
+                const f32x2 t2 = (d2[0] + d2[1]) + (d2[2] + d2[3]);
+                float mean = group_sum<LANES>(t2[0] + t2[1]) * (1.0f / IN_WAVE);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d2[i] = d2[i] - mean;
+                f32x2 q2 = d2[0] * d2[0];
+#pragma unroll
+                for (int i = 1; i < 4; ++i) q2 = q2 + d2[i] * d2[i];
+                float q = group_sum<LANES>(q2[0] + q2[1]);
+                if constexpr (GS > WTN) {
+                    if (cg == 0) { xch[(wave * RPS + rr) * 2] = mean; xch[(wave * RPS + rr) * 2 + 1] = q; }
+                    __syncthreads();
+                    const float om = xch[((wave ^ 1) * RPS + rr) * 2], oq = xch[((wave ^ 1) * RPS + rr) * 2 + 1];
+                    const float delta = om - mean;
+                    q = q + oq + delta * delta * (0.5f * IN_WAVE);
+                    const float shift = -0.5f * delta;   // old mean - merged mean
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d2[i] = d2[i] + shift;
+                }
+                const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / GS) + eps);
+                bf16x8 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x2 a2 = f32x2{gam[2 * i], gam[2 * i + 1]} * rstd;
+                    const f32x2 y2 = d2[i] * a2 + f32x2{bet[2 * i], bet[2 * i + 1]};
+                    f32x2 e2 = y2 * -1.4426950408889634f;
+                    e2 = f32x2{__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])} + 1.0f;
+                    const f32x2 o2 = y2 * f32x2{__builtin_amdgcn_rcpf(e2[0]), __builtin_amdgcn_rcpf(e2[1])};
+                    o[2 * i] = (bf16_t)o2[0];
+                    o[2 * i + 1] = (bf16_t)o2[1];
+                }
+                if (live) *reinterpret_cast<bf16x8*>(dst) = o;
+                return;
+            }
             float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
             s = group_sum<LANES>(s);
             float mean = s * (1.0f / IN_WAVE);

@@ -26,7 +26,7 @@ import adcdiff  # noqa: E402
 from adcdiff import _lib, ops  # noqa: E402
 
 WORKLOADS = {
-    # name: (compute dtype, per-GPU batch, BASELINE.json config it implements)
+    # name: (compute dtype, per-GPU batch, description of the configuration)
     "bf16_b65536": ("bf16", 65536, "configs[2]: bf16 MFMA denoiser GEMMs, batch 65536 on 1 MI355X"),
     "fp32_b4096": ("fp32", 4096, "configs[1]: same denoiser, fp32 on 1 MI355X, batch 4096"),
 }
