@@ -95,3 +95,35 @@ def test_training_workspace_grows_affinely_with_batch():
         assert max(d) - min(d) <= 0.02 * min(d)
         # forward tape alone keeps >= 30 row-sized activations of width >= 256 per block pair
         assert b[1] > 4096 * 256 * 4 * 100
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """Every struct that crosses the C ABI: size and field offsets as gcc lays out include/adcdiff.h against the ctypes
+    mirror in adcdiff._lib (a silent mismatch would shift every later argument)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from adcdiff import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    pairs = [("adcdiff_gn_out", _lib.GnOut), ("adcdiff_gemm_args", _lib.GemmArgs), ("adcdiff_ddpm_coef", _lib.DdpmCoef),
+             ("adcdiff_ddim_coef", _lib.DdimCoef), ("adcdiff_block_params", _lib.BlockParams), ("adcdiff_unet_params", _lib.UnetParams),
+             ("adcdiff_block_grads", _lib.BlockGrads), ("adcdiff_unet_grads", _lib.UnetGrads), ("adcdiff_timing_record", _lib.TimingRecord),
+             ("adcdiff_opt_tensor", _lib.OptTensor), ("adcdiff_adamw_args", _lib.AdamWArgs)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "adcdiff.h"', 'int main(void) {']
+    for cname, ct in pairs:
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in ct._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out.strip().splitlines()}
+    for cname, ct in pairs:
+        assert got[(cname, "size")] == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert got[(cname, fname)] == getattr(ct, fname).offset, (cname, fname)
