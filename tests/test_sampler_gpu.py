@@ -176,3 +176,24 @@ def test_unfused_path_for_non_power_of_two_groups(dtype):
     s = ddpm.make_schedule()
     ref = ddpm.p_sample_loop(w, s, ddpm.philox_x_T(SEED, 0, 16, 192), None, ddpm.philox_noise_fn(SEED, 0, 16, 192), t_start=999, t_stop=950)
     assert rel_err(out, ref) < LOOP_TOL[dtype]
+
+
+def test_generator_driver_latents_and_summaries(golden_a):
+    """The generator's sampling half on the GPU (molecule_generator.py:155-262): batches of generation_batch_size with a
+    one-row protein condition expanded to the batch, DDIM 50 steps; with a seed the concatenated batches equal one sample()
+    call over all rows (noise is keyed by global row).  Then the on-GPU reduction to the five numbers the latent -> SMILES
+    heuristic reads: bit-exact against numpy on the latents, and smiles_candidates against the oracle's restatement."""
+    from oracle import latent
+    from adcdiff.generation.molecule_generator import MoleculeGenerator
+    m, _ = build((512, 256, 512), "fp32")
+    gen = MoleculeGenerator({"generation_batch_size": 32, "ddim_steps": 50})
+    gen.set_diffusion_model(m)
+    protein = cu(philox.normal(SEED, 51, 0, 0, 1, 512))[0]            # 1-D condition, as the reference accepts
+    feats = gen.generate_initial_features(70, protein_features=protein, seed=SEED)   # 32 + 32 + 6 rows
+    assert feats.shape == (70, 512) and feats.dtype == torch.float32 and torch.isfinite(feats).all()
+    whole = m.sample(70, condition=protein.unsqueeze(0).repeat(70, 1), use_ddim=True, ddim_steps=50, seed=SEED)
+    assert torch.equal(feats, whole)
+    summ = gen.latent_summaries(feats).cpu().numpy()
+    assert summ.tobytes() == latent.summaries(feats.cpu().numpy()).tobytes()
+    for row in summ:
+        assert MoleculeGenerator.smiles_candidates(row) == latent.decode_candidates(row)
