@@ -18,7 +18,7 @@ class GnOut(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("m_valid", C.c_int), ("nseg", C.c_int),
                 ("A", c_fp * 3), ("lda", C.c_int * 3), ("K", C.c_int * 3), ("W", c_fp), ("ldw", C.c_int),
-                ("bias", c_fp), ("rowbias", c_fp), ("ldrb", C.c_longlong), ("rowbias_idx", c_fp),
+                ("bias", c_fp), ("rowbias", c_fp), ("ldrb", C.c_longlong), ("rowbias_idx", c_fp), ("rowbias_rows", C.c_int),
                 ("residual", c_fp), ("ldr", C.c_int), ("act", C.c_int), ("out_f32", c_fp), ("ldo_f32", C.c_int),
                 ("out_op", c_fp), ("ldo_op", C.c_int), ("n_gn", C.c_int), ("gn", GnOut * 2), ("gn_eps", C.c_float), ("tile_hint", C.c_int),
                 ("split_k", C.c_int), ("split_stride", C.c_longlong)]

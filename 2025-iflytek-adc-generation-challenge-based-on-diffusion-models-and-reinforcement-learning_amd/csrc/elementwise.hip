@@ -229,12 +229,13 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__
                                                        const float* __restrict__ sqrt_ac, const float* __restrict__ sqrt_1mac,
                                                        const float* __restrict__ noise, int ldn, float* __restrict__ out, int ldo,
                                                        float* __restrict__ noise_out, int ldno, long total4, int q4, uint64_t seed,
-                                                       uint32_t step, uint64_t row_offset) {
+                                                       uint32_t step, uint64_t row_offset, int num_timesteps) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total4) return;
     const long row = e / q4;
     const int quad = (int)(e - row * q4);
-    const long tr = t[row];
+    long tr = t[row];
+    tr = tr < 0 ? 0 : tr >= num_timesteps ? num_timesteps - 1 : tr;   // never read outside the schedule tables
     const float a = sqrt_ac[tr], s = sqrt_1mac[tr];
     const f32x4 xv = *reinterpret_cast<const f32x4*>(x0 + row * ldx + quad * 4);
     f32x4 z;
@@ -264,14 +265,15 @@ __global__ __launch_bounds__(256) void sinusoid_kernel(float* __restrict__ out, 
 // s[r, :] = SiLU(te_table[t_r, :] + cemb[r, :]) in the GEMM operand type: the A operand of time_proj
 // (diffusion_model.py:766, 859-862) when a condition makes the time term row dependent.
 template <typename OutT>
-__global__ __launch_bounds__(256) void temb_silu_kernel(const float* __restrict__ te_table, int ldt, const int64_t* __restrict__ t_rows,
-                                                        int t_uniform, const float* __restrict__ cemb, int ldce,
+__global__ __launch_bounds__(256) void temb_silu_kernel(const float* __restrict__ te_table, int ldt, int table_rows,
+                                                        const int64_t* __restrict__ t_rows, int t_uniform, const float* __restrict__ cemb, int ldce,
                                                         OutT* __restrict__ out, int ldo, int rows, int H) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long)rows * H) return;
     const long r = e / H;
     const int j = (int)(e - r * H);
-    const long t = t_rows ? (long)t_rows[r] : (t_uniform < 0 ? r : (long)t_uniform);   // t_uniform < 0: row r is timestep r
+    long t = t_rows ? (long)t_rows[r] : (t_uniform < 0 ? r : (long)t_uniform);   // t_uniform < 0: row r is timestep r
+    t = t < 0 ? 0 : t >= table_rows ? table_rows - 1 : t;                        // never read outside the table
     float v = te_table[t * ldt + j];
     if (cemb) v = v + cemb[r * ldce + j];
     out[r * ldo + j] = (OutT)silu_f(v);
@@ -299,15 +301,15 @@ int sinusoid_table(float* out, int ld, int rows, int half, const float* freq, hi
     return check_launch("sinusoid");
 }
 
-int temb_silu(const float* te_table, int ldt, const int64_t* t_rows, int t_uniform, const float* cemb, int ldce, int dtype,
+int temb_silu(const float* te_table, int ldt, int table_rows, const int64_t* t_rows, int t_uniform, const float* cemb, int ldce, int dtype,
               void* out, int ldo, int rows, int H, hipStream_t stream) {
     const long total = (long)rows * H;
     const dim3 grid((unsigned)((total + 255) / 256));
     if (dtype == ADCDIFF_BF16)
-        hipLaunchKernelGGL((temb_silu_kernel<bf16_t>), grid, dim3(256), 0, stream, te_table, ldt, t_rows, t_uniform, cemb, ldce,
+        hipLaunchKernelGGL((temb_silu_kernel<bf16_t>), grid, dim3(256), 0, stream, te_table, ldt, table_rows, t_rows, t_uniform, cemb, ldce,
                            reinterpret_cast<bf16_t*>(out), ldo, rows, H);
     else
-        hipLaunchKernelGGL((temb_silu_kernel<float>), grid, dim3(256), 0, stream, te_table, ldt, t_rows, t_uniform, cemb, ldce,
+        hipLaunchKernelGGL((temb_silu_kernel<float>), grid, dim3(256), 0, stream, te_table, ldt, table_rows, t_rows, t_uniform, cemb, ldce,
                            reinterpret_cast<float*>(out), ldo, rows, H);
     return check_launch("temb_silu");
 }
@@ -397,10 +399,10 @@ extern "C" int adcdiff_q_sample(const float* x0, int ldx, const int64_t* t, cons
     const dim3 grid((unsigned)((total4 + 255) / 256));
     if (noise)
         hipLaunchKernelGGL((q_sample_kernel<true>), grid, dim3(256), 0, as_stream(stream), x0, ldx, t, sqrt_ac, sqrt_one_minus_ac,
-                           noise, ldn, out, ldo, noise_out, ldno, total4, D / 4, seed, step, row_offset);
+                           noise, ldn, out, ldo, noise_out, ldno, total4, D / 4, seed, step, row_offset, num_timesteps);
     else
         hipLaunchKernelGGL((q_sample_kernel<false>), grid, dim3(256), 0, as_stream(stream), x0, ldx, t, sqrt_ac, sqrt_one_minus_ac,
-                           noise, ldn, out, ldo, noise_out, ldno, total4, D / 4, seed, step, row_offset);
+                           noise, ldn, out, ldo, noise_out, ldno, total4, D / 4, seed, step, row_offset, num_timesteps);
     return check_launch("q_sample");
 }
 

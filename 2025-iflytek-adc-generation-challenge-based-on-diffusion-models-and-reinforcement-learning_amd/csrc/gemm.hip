@@ -44,6 +44,7 @@ struct GemmParams {
     const float* rowbias;
     long long ldrb;
     const int64_t* rowbias_idx;
+    int rowbias_rows;
     const void* residual;   // operand type
     int ldr;
     int act;
@@ -304,7 +305,8 @@ struct Epilogue {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += cb[k];
         if (row_rb) {
-            const long ridx = p.rowbias_idx ? (long)p.rowbias_idx[lrow] : lrow;
+            long ridx = p.rowbias_idx ? (long)p.rowbias_idx[lrow] : lrow;
+            if (p.rowbias_rows > 0) ridx = ridx < 0 ? 0 : ridx >= p.rowbias_rows ? p.rowbias_rows - 1 : ridx;   // never read outside the table
             float t[8];
             load8(p.rowbias + ridx * p.ldrb + col, t);
 #pragma unroll
@@ -920,6 +922,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     if (a.split_k > 1) p.ktiles[0] = kslice / bk;
     p.m_valid = a.m_valid == 0 ? a.M : a.m_valid;
     p.bias = a.bias; p.rowbias = a.rowbias; p.ldrb = a.ldrb; p.rowbias_idx = a.rowbias_idx;
+    p.rowbias_rows = a.rowbias_idx ? a.rowbias_rows : 0;
     p.residual = a.residual; p.ldr = a.ldr; p.act = a.act;
     p.out_f32 = a.out_f32; p.ldo_f32 = a.ldo_f32;
     p.out_op = a.out_op; p.ldo_op = a.ldo_op;

@@ -186,12 +186,14 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const float* __restrict__
 
 // table[t[r], col0 + c] += src[r, c]
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, long lds_, const int64_t* __restrict__ t, int rows,
-                                                               int cols, float* __restrict__ table, long ldt, int col0) {
+                                                               int cols, float* __restrict__ table, long ldt, int col0, int table_rows) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long)rows * cols) return;
     const long r = e / cols;
     const int c = (int)(e - r * cols);
-    atomicAdd(table + (long)t[r] * ldt + col0 + c, src[r * lds_ + c]);
+    long tr = t[r];
+    tr = tr < 0 ? 0 : tr >= table_rows ? table_rows - 1 : tr;   // as the forward pass clamps it
+    atomicAdd(table + tr * ldt + col0 + c, src[r * lds_ + c]);
 }
 
 // d_pred = 2 * scale * (pred - target) / n;  *loss += scale * sum((target - pred)^2) / n   (F.mse_loss, mean reduction)
@@ -480,7 +482,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             const long total = (long)B * cout;
             if (!dry) {
                 hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_h1, (long)cout, tp.t_rows, B,
-                                   cout, d_tb, (long)SN, b.tb_off);
+                                   cout, d_tb, (long)SN, b.tb_off, n->T);
                 TRY(check_launch("scatter_add_rows"));
             }
         }

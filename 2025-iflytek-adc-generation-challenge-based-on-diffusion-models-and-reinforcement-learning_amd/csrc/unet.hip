@@ -152,13 +152,13 @@ extern "C" int adcdiff_unet_pack(adcdiff_unet* n, void* workspace, size_t worksp
     g.nseg = 1; g.A[0] = n->sin_table; g.lda[0] = H; g.K[0] = H; g.W = p.time_lin1_w; g.ldw = H; g.bias = p.time_lin1_b;
     g.out_f32 = n->te_pre; g.ldo_f32 = 4 * H;   // pre-activation kept for the training step's backward
     TRY(gemm_dispatch(g, st));
-    TRY(temb_silu(n->te_pre, 4 * H, nullptr, -1, nullptr, 0, ADCDIFF_F32, n->te_hidden, 4 * H, n->Tp, 4 * H, st));
+    TRY(temb_silu(n->te_pre, 4 * H, n->Tp, nullptr, -1, nullptr, 0, ADCDIFF_F32, n->te_hidden, 4 * H, n->Tp, 4 * H, st));
     g = gemm_args(ADCDIFF_F32, n->Tp, 0, H);
     g.nseg = 1; g.A[0] = n->te_hidden; g.lda[0] = 4 * H; g.K[0] = 4 * H; g.W = p.time_lin2_w; g.ldw = 4 * H; g.bias = p.time_lin2_b;
     g.out_f32 = n->te_table; g.ldo_f32 = H;
     TRY(gemm_dispatch(g, st));
     // every block's time_proj(SiLU(t_emb)) for every timestep (diffusion_model.py:859-862, 893)
-    TRY(temb_silu(n->te_table, H, nullptr, -1, nullptr, 0, ADCDIFF_F32, n->s_table, H, n->Tp, H, st));
+    TRY(temb_silu(n->te_table, H, n->Tp, nullptr, -1, nullptr, 0, ADCDIFF_F32, n->s_table, H, n->Tp, H, st));
     g = gemm_args(ADCDIFF_F32, n->Tp, 0, n->sumN);
     g.nseg = 1; g.A[0] = n->s_table; g.lda[0] = H; g.K[0] = H; g.W = n->wtp_all; g.ldw = H; g.bias = n->btp_all;
     g.out_f32 = n->tb_table; g.ldo_f32 = n->sumN;
@@ -190,7 +190,7 @@ int adcdiff::forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, co
     const void* s_op = nullptr;
     if (cond || dry) {   // the dry run sizes for the conditional case, the larger one
         void* s = ws.take((size_t)Bp * H * e);
-        if (!dry) TRY(temb_silu(n->te_table, H, t_rows, t_uniform, cemb, ldce, dt, s, H, B, H, st));
+        if (!dry) TRY(temb_silu(n->te_table, H, n->T, t_rows, t_uniform, cemb, ldce, dt, s, H, B, H, st));
         s_op = s;
     }
 
@@ -232,7 +232,7 @@ int adcdiff::forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, co
                 g.bias = b.bias1_cond;
             } else {
                 g.bias = b.bias1;
-                if (t_rows) { g.rowbias = n->tb_table + b.tb_off; g.ldrb = n->sumN; g.rowbias_idx = t_rows; }
+                if (t_rows) { g.rowbias = n->tb_table + b.tb_off; g.ldrb = n->sumN; g.rowbias_idx = t_rows; g.rowbias_rows = n->T; }
                 else { g.rowbias = n->tb_table + (size_t)t_uniform * n->sumN + b.tb_off; g.ldrb = 0; }
             }
             g.out_f32 = h1; g.ldo_f32 = b.cout;
@@ -305,7 +305,7 @@ int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t
     const void* s_op = nullptr;
     if (cond || dry) {
         void* s = ws.take((size_t)Bp * H * e);
-        if (!dry) TRY(temb_silu(n->te_table, H, t_rows, t_uniform, cemb, ldce, dt, s, H, B, H, st));
+        if (!dry) TRY(temb_silu(n->te_table, H, n->T, t_rows, t_uniform, cemb, ldce, dt, s, H, B, H, st));
         s_op = s;
     }
     // the latent enters through the one stand-alone GroupNorm of the step: encoder.0's norm1 (diffusion_model.py:888-889)
@@ -335,7 +335,7 @@ int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t
                 g.bias = b.bias1_cond;
             } else {
                 g.bias = b.bias1;
-                if (t_rows) { g.rowbias = n->tb_table + b.tb_off; g.ldrb = n->sumN; g.rowbias_idx = t_rows; }
+                if (t_rows) { g.rowbias = n->tb_table + b.tb_off; g.ldrb = n->sumN; g.rowbias_idx = t_rows; g.rowbias_rows = n->T; }
                 else { g.rowbias = n->tb_table + (size_t)t_uniform * n->sumN + b.tb_off; g.ldrb = 0; }
             }
             g.n_gn = 1; g.gn_eps = 1e-5f;

@@ -12,7 +12,7 @@ int groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const floa
                    int out_dtype, void* out, int ldo, void* raw_out, int ldraw, hipStream_t stream, float drop_p = 0.0f,
                    uint64_t drop_seed = 0, uint32_t drop_layer = 0);
 int sinusoid_table(float* out, int ld, int rows, int half, const float* freq, hipStream_t stream);
-int temb_silu(const float* te_table, int ldt, const int64_t* t_rows, int t_uniform, const float* cemb, int ldce, int dtype,
+int temb_silu(const float* te_table, int ldt, int table_rows, const int64_t* t_rows, int t_uniform, const float* cemb, int ldce, int dtype,
               void* out, int ldo, int rows, int H, hipStream_t stream);
 int cast_pack(const float* src, int lds_, int dtype, void* dst, int ldd, int col0, int rows, int cols, hipStream_t stream);
 int add_vec(const float* a, const float* b, float* out, int n, hipStream_t stream);

@@ -72,6 +72,7 @@ def gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, ac
         args.rowbias = rowbias.data_ptr()
         args.ldrb = 0 if rowbias.dim() == 1 else rowbias.stride(0)
     args.rowbias_idx = rowbias_idx.data_ptr() if rowbias_idx is not None else None
+    args.rowbias_rows = rowbias.shape[0] if (rowbias_idx is not None and rowbias is not None and rowbias.dim() == 2) else 0
     if residual is not None:
         args.residual, args.ldr = residual.data_ptr(), residual.stride(0)
     args.act = act

@@ -79,6 +79,8 @@ typedef struct adcdiff_gemm_args {
                                   ldrb == 0 broadcasts one row (the hoisted time_proj term, :893) */
     long long ldrb;
     const int64_t* rowbias_idx;/* [M] timestep per row, or NULL */
+    int rowbias_rows;          /* rows of the rowbias table when rowbias_idx is given: indices are clamped to 0..rowbias_rows-1
+                                  (the reference raises an IndexError there; a kernel must not read out of bounds); 0 = no clamp */
     const void* residual;      /* [M, N] in the operand type, added to v (Identity residual, :873), or NULL */
     int ldr;
     int act;                   /* 0 none, 1 SiLU on v before it is stored (:820); not combined with gn outputs */
@@ -128,7 +130,7 @@ int adcdiff_ddim_step(const float* x, int ldx, const float* eps, int lde, const 
                       float* out, int ldo, int B, int D, adcdiff_ddim_coef coef, uint64_t seed,
                       uint32_t step, uint64_t row_offset, adcdiff_stream_t stream);
 
-/* Forward diffusion with per-row timesteps (diffusion_model.py:144-163):
+/* Forward diffusion with per-row timesteps (diffusion_model.py:144-163); timesteps outside 0..num_timesteps-1 are clamped:
  *   out = sqrt_ac[t_r] * x0 + sqrt_one_minus_ac[t_r] * z;  z = noise or Philox (ADCDIFF_STREAM_QNOISE, step).
  * When noise_out != NULL the z that was used is written there (p_losses needs it as the target, :176-183). */
 int adcdiff_q_sample(const float* x0, int ldx, const int64_t* t, const float* sqrt_ac, const float* sqrt_one_minus_ac,

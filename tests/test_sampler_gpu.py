@@ -197,3 +197,19 @@ def test_generator_driver_latents_and_summaries(golden_a):
     assert summ.tobytes() == latent.summaries(feats.cpu().numpy()).tobytes()
     for row in summ:
         assert MoleculeGenerator.smiles_candidates(row) == latent.decode_candidates(row)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_out_of_range_timesteps_are_clamped(dtype):
+    """Per-row timesteps index tables on the device (the hoisted time branch, the schedule tables of q_sample); a value
+    outside 0..T-1 must not read outside them.  It is clamped: rows with t = -1, T, T + 1 equal rows with t = 0, T-1, T-1
+    (the values are chosen so that even an unclamped read would stay inside the padded tables)."""
+    m, _ = build((128, 128, 128), dtype)
+    x = cu(philox.normal(SEED, 50, 0, 0, 6, 128))
+    cond = cu(philox.normal(SEED, 51, 0, 0, 6, 128))
+    bad = torch.tensor([-1, 1000, 1001, 5, 0, 999], device="cuda", dtype=torch.int64)
+    good = torch.tensor([0, 999, 999, 5, 0, 999], device="cuda", dtype=torch.int64)
+    assert torch.equal(m.model(x, bad), m.model(x, good))
+    assert torch.equal(m.model(x, bad, cond), m.model(x, good, cond))
+    nz = cu(philox.normal(SEED, philox.STREAM_QNOISE, 0, 0, 6, 128))
+    assert torch.equal(m.q_sample(x, bad, nz), m.q_sample(x, good, nz))
