@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libadcdiff.so")
+LIB_PATH = os.environ.get("ADCDIFF_LIB") or os.path.join(HERE, "libadcdiff.so")   # ADCDIFF_LIB: an instrumented build (measurement aid)
 
 F32, BF16 = 0, 1
 STREAM_XT, STREAM_STEP, STREAM_QNOISE, STREAM_TDRAW = 1, 2, 3, 4

@@ -790,14 +790,174 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmParams p
 #endif
 }
 
-static int launch256(const GemmParams& p, hipStream_t stream) {
-    constexpr int smem = 2 * 65536 + Epilogue<bf16_t, 512, 256, 128, 64, 8, 4>::EXTRA_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
+// Ring main loop: K is consumed in steps of 32 (ONE v_mfma_f32_16x16x32_bf16 per 16 x 16 output tile and step, so all 32
+// MFMAs of a wave's step are independent).  A step's operands -- 256 rows of A and 256 rows of W, 64 bytes each -- form one
+// 32 KiB LDS region (rows of 64 bytes, four 16-byte chunks, physical chunk = logical chunk ^ g((row >> 2) & 3) with
+// g = {0, 2, 3, 1}: the four 16-lane groups of a ds_read_b128 then hit sixteen distinct 16-byte slots of a bank row); four
+// regions form a ring.  During step R a wave issues the MFMAs of step R from registers, reads the fragments of step R + 1
+// (region R + 1) into its second register set behind every second MFMA, and issues its four LDS-DMA pieces of region
+// R + 4 into the buffer of region R, whose reads were retired (lgkmcnt(0)) before the barrier that ended step R - 1.  At
+// the end of the step it retires its reads, waits until its own pieces of region R + 2 have landed (counted vmcnt: regions
+// R + 3 and R + 4 stay in flight) and meets the other waves at the ONE barrier of the step; region R + 2 is first read in
+// step R + 1, i.e. after that barrier.  Waves 0-3 load the A rows, waves 4-7 the W rows (four 16-row pieces each per region).
+// The K order seen by every accumulator (32-wide steps in order, k = 8 * (lane >> 4) + j inside an MFMA) is the one of
+// gemm_nt_kernel, so results are bit-identical between the tilings.
+__device__ __forceinline__ int ring_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+__global__ __launch_bounds__(512, 2) void gemm256r_bf16_kernel(const GemmParams p) {
+    typedef bf16_t T;
+    constexpr int BN = 256, WTM = 128, WTN = 64, TM = 8, TN = 4, REGION = 32768, PPW = 4;
+    typedef Epilogue<T, 512, BN, WTM, WTN, TM, TN> Epi;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const prm = reinterpret_cast<float*>(smem + 4 * REGION);
+    float* const xch = prm + 5 * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+#ifdef ADCDIFF_STAMPS
+    const long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int m0 = (bid / p.ntn) * 256, n0 = (bid % p.ntn) * 256;
+    Epi::stage_params(p, n0, tid, prm);
+
+    // LDS-DMA geometry.  A piece is 16 rows x 64 bytes (1 KiB): lane l fills row l >> 2, chunk position l & 3, which holds
+    // the logical chunk (l & 3) ^ g(row) -- the swizzle sits in the SOURCE address, the LDS image stays lane-linear.
+    // g depends on bits 2..3 of the row only, i.e. on the lane, not on the piece.
+    const bool loads_a = wave < 4;
+    const int prow = lane >> 2;
+    const int piece0 = (wave & 3) * PPW;      // this wave's pieces are rows 16 * piece0 .. 16 * piece0 + 63 of its operand
+    const unsigned chunk_b = (unsigned)(((lane & 3) ^ ring_swz(prow)) * 16);
+    const long ksplit_off = (long)blockIdx.y * p.split_k_bytes;   // split-K slice of the (single) K segment
+    const int nR = 2 * p.nt_total;
+    // K segments in regions: W is one run of K; the A loaders switch operand at rs1 / rs2
+    const int rs1 = loads_a ? 2 * p.ktiles[0] : 0x7fffffff, rs2 = loads_a ? 2 * (p.ktiles[0] + p.ktiles[1]) : 0x7fffffff;
+    long ld2[3];              // row pitch in bytes
+    const char* sbase[3];     // piece 0, lane row 0, region 0 of the segment
+    unsigned voff[3];         // per-lane byte offset inside a piece
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        ld2[s] = loads_a ? (long)p.lda[s] * 2 : (long)p.ldw * 2;
+        sbase[s] = loads_a ? reinterpret_cast<const char*>(p.A[s]) + (long)(m0 + 16 * piece0) * ld2[s] + (s == 0 ? ksplit_off : 0)
+                           : reinterpret_cast<const char*>(p.W) + (long)(n0 + 16 * piece0) * ld2[s] + ksplit_off;
+        voff[s] = (unsigned)prow * (unsigned)ld2[s] + chunk_b;
     }
+    const unsigned dst0 = lds0 + (loads_a ? 0 : 16384) + piece0 * 1024;
+    // piece J of region G
+#define ADCDIFF_R_ISSUE1(G, J)                                                                                      \
+    do {                                                                                                           \
+        const int g_ = (G);                                                                                        \
+        if (g_ < nR) {                                                                                             \
+            const int seg_ = g_ < rs1 ? 0 : g_ < rs2 ? 1 : 2;                                                      \
+            const int kk_ = g_ - (seg_ == 0 ? 0 : seg_ == 1 ? rs1 : rs2);                                          \
+            const char* b_ = (seg_ == 0 ? sbase[0] : seg_ == 1 ? sbase[1] : sbase[2]) + (long)kk_ * 64 +           \
+                             (long)(16 * (J)) * (seg_ == 0 ? ld2[0] : seg_ == 1 ? ld2[1] : ld2[2]);                \
+            glds16_untracked(b_ + (seg_ == 0 ? voff[0] : seg_ == 1 ? voff[1] : voff[2]), dst0 + (g_ & 3) * REGION + (J) * 1024); \
+        }                                                                                                          \
+    } while (0)
+    // at most N of the regions this wave has issued (PPW pieces each) may still be in flight
+#define ADCDIFF_R_INFLIGHT(N)                                                                                       \
+    do {                                                                                                           \
+        const int n_ = (N);                                                                                        \
+        if (n_ >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                             \
+        else if (n_ == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                         \
+        else if (n_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                         \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+    } while (0)
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // fragment addressing: lane holds row (l & 15) and k chunk (l >> 4) of a 16-row fragment
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int a_off = (wm * WTM + frow) * 64 + ((fchunk ^ ring_swz(frow)) << 4);
+    const int b_off = 16384 + (wn * WTN + frow) * 64 + ((fchunk ^ ring_swz(frow)) << 4);
+    uint4 fa[2][TM], fb[2][TN];   // two register sets: one feeds the MFMAs of the step, the other receives the next step's reads
+#define ADCDIFF_R_READ(S, RB, X)                                                                                    \
+    do {                                                                                                           \
+        if ((X) < TN) fb[S][(X) < TN ? (X) : 0] = *reinterpret_cast<const uint4*>((RB) + b_off + ((X) < TN ? (X) : 0) * 1024); \
+        else fa[S][(X) >= TN ? (X) - TN : 0] = *reinterpret_cast<const uint4*>((RB) + a_off + ((X) >= TN ? (X) - TN : 0) * 1024); \
+    } while (0)
+    // One step.  S = register set holding step R's fragments.  32 MFMAs; read X of the 12 fragment reads of step R + 1 goes
+    // out behind MFMA 2 X + 1, DMA piece J of region R + 4 behind MFMA 8 J + 4.
+#define ADCDIFF_R_STEP(R_, S)                                                                                       \
+    do {                                                                                                           \
+        const int r_ = (R_);                                                                                       \
+        const char* rb_ = smem + ((r_ + 1) & 3) * REGION;                                                          \
+        const bool more_ = r_ + 1 < nR;                                                                            \
+        _Pragma("unroll") for (int x = 0; x < TM * TN; ++x) {                                                      \
+            const int i = x / TN, j = (x / TN) & 1 ? TN - 1 - x % TN : x % TN;                                     \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[S][i]),              \
+                                                                __builtin_bit_cast(bf16x8, fb[S][j]), acc[i][j], 0, 0, 0); \
+            if (more_ && (x & 1) && x / 2 < TM + TN) ADCDIFF_R_READ((S) ^ 1, rb_, x / 2);                           \
+            if (x % 8 == 4) ADCDIFF_R_ISSUE1(r_ + 4, x / 8);                                                       \
+            if (x & 1) __builtin_amdgcn_sched_barrier(0);                                                          \
+        }                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+        ADCDIFF_R_INFLIGHT(nR - 3 - r_ < 2 ? nR - 3 - r_ : 2);   /* regions r + 3, r + 4 may stay in flight */      \
+        __builtin_amdgcn_s_barrier();                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    } while (0)
+
+    // prologue: four regions under way; region 0 landed -> its fragments into set 0; region 1 landed
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) ADCDIFF_R_ISSUE1(g, j);
+    }
+    ADCDIFF_R_INFLIGHT(nR - 1 < 3 ? nR - 1 : 3);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int x = 0; x < TM + TN; ++x) ADCDIFF_R_READ(0, smem, x);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ADCDIFF_R_INFLIGHT(nR - 2 < 2 ? nR - 2 : 2);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef ADCDIFF_STAMPS
+    const long long st1 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int r = 0; r < nR; r += 2) {   // nR is even: a K tile of 64 is two steps
+        ADCDIFF_R_STEP(r, 0);
+        ADCDIFF_R_STEP(r + 1, 1);
+    }
+#undef ADCDIFF_R_STEP
+#undef ADCDIFF_R_READ
+#undef ADCDIFF_R_INFLIGHT
+#undef ADCDIFF_R_ISSUE1
+    __syncthreads();
+#ifdef ADCDIFF_STAMPS
+    const long long st2 = __builtin_amdgcn_s_memtime();
+#endif
+    Epi::template run<true>(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
+#ifdef ADCDIFF_STAMPS
+    const long long st3 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long st4 = __builtin_amdgcn_s_memtime(), rt4 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && blockIdx.x < 8192) {
+        long long* o = p.stamps + ((long)blockIdx.x * 8 + wave) * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = rt0; o[6] = rt4; o[7] = 0;
+    }
+#endif
+}
+
+// pipelined = the ring main loop (gemm256r_bf16_kernel), else the two-group phased loop
+static int launch256(const GemmParams& p, bool pipelined, hipStream_t stream) {
+    constexpr int smem = 2 * 65536 + Epilogue<bf16_t, 512, 256, 128, 64, 8, 4>::EXTRA_BYTES;
+    // once per process, thread-safe (initialisation of a function-local static)
+    static const hipError_t attr_err = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256r_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        return e;
+    }();
+    if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmParams q = p;
     q.ntn = p.N / 256;
 #ifdef ADCDIFF_STAMPS
@@ -806,7 +966,8 @@ static int launch256(const GemmParams& p, hipStream_t stream) {
     q.stamps = dbuf;
 #endif
     const int grid = (p.M / 256) * q.ntn;
-    hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(grid, p.ksplit), dim3(512), smem, stream, q);
+    if (pipelined) hipLaunchKernelGGL(gemm256r_bf16_kernel, dim3(grid, p.ksplit), dim3(512), smem, stream, q);
+    else hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(grid, p.ksplit), dim3(512), smem, stream, q);
 #ifdef ADCDIFF_STAMPS
     {
         static int calls = 0;
@@ -839,13 +1000,9 @@ static int launch(const GemmParams& p, hipStream_t stream) {
     typedef Epilogue<T, 256, BN, BM / 2, BN / 2, BM / 2 / TS, BN / 2 / TS> Epi;
     constexpr int main_bytes = NSTAGE * (BM + BN) * 128;
     constexpr int smem = (main_bytes > Epi::STAGE_BYTES ? main_bytes : Epi::STAGE_BYTES) + Epi::EXTRA_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN, NSTAGE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, BM, BN, NSTAGE>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmParams q = p;
     q.ntn = p.N / BN;
     const int grid = (p.M / BM) * q.ntn;
@@ -932,12 +1089,16 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     // 256 x 256 kernel (one workgroup per CU, prefetch under the MFMAs, rolled epilogue) wins once the K loop is long
     // enough to amortise its exposed prologue / epilogue, and where the epilogue is the larger part (three outputs from
     // K >= 768); the 128-row kernel (3-4 workgroups per CU) wins elsewhere.
-    bool big = false;
+    bool big = false, pipelined = false;
+    // measurement aid: ADCDIFF_GEMM_RING=1 selects the ring main loop for every 256-tile launch (tile_hint 2561 does per call);
+    // the two-group phased loop is the default: same cycles per tile within 1 %, but the chip holds a higher clock on it
+    static const bool pipe_default = [] { const char* e = getenv("ADCDIFF_GEMM_RING"); return e ? atoi(e) != 0 : false; }();
     if (a.dtype == ADCDIFF_BF16 && a.M % 256 == 0 && a.N % 256 == 0 && a.tile_hint != 128) {
         static const int forced = [] { const char* e = getenv("ADCDIFF_GEMM_TILE"); return e ? atoi(e) : 0; }();   // measurement aid
         const bool enough_tiles = forced != 128 && (long)(a.M / 256) * (a.N / 256) * p.ksplit >= 192;
         const bool long_k = kslice >= 2048 || (nout >= 3.0 * esz && kslice >= 768);
-        big = forced == 256 || a.tile_hint == 256 || (enough_tiles && long_k);
+        big = forced == 256 || forced == 2561 || a.tile_hint == 256 || a.tile_hint == 2561 || a.tile_hint == 2560 || (enough_tiles && long_k);
+        pipelined = a.tile_hint == 2561 || (a.tile_hint != 2560 && pipe_default);
     }
     // few rows (the float32 batch-4096 case, small generation batches): 64 x 64 tiles give four times the workgroups
     bool small = (long)(a.M / 128) * (a.N / (wide ? 128 : 64)) * p.ksplit < 256 && a.tile_hint != 128 && a.tile_hint != 1 && a.tile_hint != 3;
@@ -947,7 +1108,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     const int kind = a.dtype == ADCDIFF_F32 ? ADCDIFF_KIND_GEMM_F32 : big ? ADCDIFF_KIND_GEMM_BF16_T256 : ADCDIFF_KIND_GEMM_BF16;
     TimingScope ts(kind, a.M, a.N, ktot, 2.0 * a.M * a.N * ktot,
                    esz * ((double)a.M * ktot + (double)a.N * ktot) + (double)a.M * a.N * (nout + (a.residual ? esz : 0.0)), stream);
-    if (big) return launch256(p, stream);
+    if (big) return launch256(p, pipelined, stream);
     // few workgroups: nothing else on the CU hides a tile's load latency, so take the three-stage ring
     const int bn = small ? 64 : wide ? 128 : 64, bm = small ? 64 : 128;
     const long blocks = (long)(a.M / bm) * (a.N / bn) * p.ksplit;

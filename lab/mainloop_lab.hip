@@ -1,0 +1,308 @@
+// Main-loop laboratory for the 256 x 256-tile bf16 GEMM (gfx950): stand-alone program, no torch.
+//   C[M, N] (bf16) = A[M, K] * W[N, K]^T, M = 65536 by default.
+// Structure under test: K is consumed in steps of 32 (one v_mfma_f32_16x16x32_bf16 per 16 x 16 output tile and step).
+// A step's operands (256 rows of A and of W, 64 bytes each) form one 32 KiB LDS region; four regions form a ring.
+// During step R a wave issues the MFMAs of step R from registers, reads the fragments of step R + 1 into a second
+// register set, and issues its LDS-DMA pieces of region R + 4; one barrier per step.
+// Template parameters choose 4 waves (2 x 2, 128 x 128 per wave, one wave per SIMD, accumulators in 256 registers) or
+// 8 waves (2 x 4, 128 x 64 per wave, two waves per SIMD), and ablations (no reads / no DMA / no barrier) that show
+// what each part of a step costs.  Results are checked against a plain kernel on sampled rows.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+enum { ABL_NOREAD = 1, ABL_NODMA = 2, ABL_NOBAR = 4, ABL_NOWAIT = 8, ABL_SAMEK = 16, ABL_SAMETILE = 32, ABL_STAGGER = 64, ABL_STAGGER2 = 128 };
+
+struct Params {
+    const bf16_t* A; const bf16_t* W; bf16_t* C;
+    int M, N, K, ntn;
+    long long* stamps;
+};
+
+// chunk swizzle of the 64-byte-row image: physical chunk = logical chunk ^ g((row >> 2) & 3), g = {0, 2, 3, 1}: the four
+// 16-lane groups of a ds_read_b128 (rows l & 15, chunk l >> 4) then hit sixteen distinct 16-byte slots of a 256-byte bank row
+__device__ __forceinline__ int swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }   // 0b01111000 -> {0,2,3,1}
+
+template <int WAVES_N, int ABL, int WAVES_M = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void ring_kernel(const Params p) {
+    constexpr int NW = WAVES_M * WAVES_N, WTM = 256 / WAVES_M, WTN = 256 / WAVES_N, TM = WTM / 16, TN = WTN / 16;
+    constexpr int PPW = 32 / NW;            // LDS-DMA pieces per wave and region
+    constexpr int REGION = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int m0 = (bid / p.ntn) * 256, n0 = (bid % p.ntn) * 256;
+    const int lm0 = (ABL & ABL_SAMETILE) ? 0 : m0, ln0 = (ABL & ABL_SAMETILE) ? 0 : n0;   // load-side tile origin
+    const long long t0 = __builtin_amdgcn_s_memtime();
+
+    // DMA geometry: piece q = wave * PPW + j; q < 16: A rows 16 q .. 16 q + 15, else W rows 16 (q - 16) ..
+    const int prow = lane >> 2;
+    const char* src[PPW];
+    unsigned dst[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int q = wave * PPW + j;
+        const bool isA = q < 16;
+        const int row = 16 * (q & 15) + prow;
+        const int chunk = (lane & 3) ^ swz(row);
+        const char* base = isA ? reinterpret_cast<const char*>(p.A) + (long)(lm0 + row) * p.K * 2
+                               : reinterpret_cast<const char*>(p.W) + (long)(ln0 + row) * p.K * 2;
+        src[j] = base + chunk * 16;
+        dst[j] = (isA ? 0 : 16384) + (q & 15) * 1024;
+    }
+    const int nR = p.K / 32;
+    const int wslot = wave % (TM * TN / PPW);                 // every wave its own issue slot inside an 8-MFMA window
+    const int wslot2 = ((wave & 3) * 2 + (wave >> 2)) % (TM * TN / PPW);   // SIMD partners (w, w + 4) in adjacent slots
+    auto issue = [&](int R) {
+        if (R < nR) {
+            const unsigned rb = lds0 + (R & 3) * REGION;
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) glds16_untracked(src[j] + (long)R * 64, rb + dst[j]);
+        }
+    };
+    auto issue1 = [&](int R, int j) {
+        if (R < nR) glds16_untracked(src[j] + ((ABL & ABL_SAMEK) ? 0L : (long)R * 64), lds0 + (R & 3) * REGION + dst[j]);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int a_off = (wm * WTM + frow) * 64 + ((fchunk ^ swz(frow)) << 4);
+    const int b_off = 16384 + (wn * WTN + frow) * 64 + ((fchunk ^ swz(frow)) << 4);
+    uint4 fa[2][TM], fb[2][TN];
+
+#define READ_A(S, RB, I) fa[S][I] = *reinterpret_cast<const uint4*>((RB) + a_off + (I) * 1024)
+#define READ_B(S, RB, J) fb[S][J] = *reinterpret_cast<const uint4*>((RB) + b_off + (J) * 1024)
+#define MMA(S, I, J)                                                                                               \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[S][I]), __builtin_bit_cast(bf16x8, fb[S][J]), \
+                                                         acc[I][J], 0, 0, 0)
+
+    // prologue
+    issue(0); issue(1); issue(2); issue(3);
+    {
+        const int inflight = nR - 1 < 3 ? nR - 1 : 3;   // regions allowed to stay in flight so that region 0 has landed
+        if (inflight >= 3) wait_vmcnt<3 * PPW>(); else if (inflight == 2) wait_vmcnt<2 * PPW>(); else if (inflight == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) READ_A(0, smem, i);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) READ_B(0, smem, j);
+    if (ABL & ABL_NOREAD) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) READ_A(1, smem, i);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) READ_B(1, smem, j);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        const int inflight = nR - 2 < 2 ? nR - 2 : 2;
+        if (inflight >= 2) wait_vmcnt<2 * PPW>(); else if (inflight == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const long long t1 = __builtin_amdgcn_s_memtime();
+
+    // one step: S = register set holding step R's fragments; the other set receives step R + 1's
+#define STEP(R_, S)                                                                                                \
+    do {                                                                                                           \
+        const int R = (R_);   /* R_ must not be spelled R at the call site */                                     \
+        const char* rb = smem + ((R + 1) & 3) * REGION;                                                            \
+        const bool more = R + 1 < nR;                                                                              \
+        constexpr int NMMA = TM * TN, NRD = TM + TN;                                                               \
+        constexpr int RD_EVERY = NMMA / NRD >= 4 ? 4 : 2;       /* a read behind every RD_EVERY-th MFMA */          \
+        constexpr int DMA_EVERY = NMMA / PPW;                                                                      \
+        _Pragma("unroll") for (int x = 0; x < NMMA; ++x) {                                                         \
+            const int i = x / TN, j = (x / TN) & 1 ? TN - 1 - x % TN : x % TN;                                     \
+            MMA(S, i, j);                                                                                          \
+            if (!(ABL & ABL_NOREAD) && more && x % RD_EVERY == 1 && x / RD_EVERY < NRD) {                          \
+                const int r = x / RD_EVERY;                                                                        \
+                if (r < TN) READ_B((S) ^ 1, rb, r); else READ_A((S) ^ 1, rb, r - TN);                              \
+            }                                                                                                      \
+            if (ABL & ABL_STAGGER) { if (x % DMA_EVERY == wslot) issue1(R + 4, x / DMA_EVERY); }                   \
+            else if (ABL & ABL_STAGGER2) { if (x % DMA_EVERY == wslot2) issue1(R + 4, x / DMA_EVERY); }             \
+            else if (!(ABL & ABL_NODMA) && x % DMA_EVERY == DMA_EVERY / 2) issue1(R + 4, x / DMA_EVERY);           \
+            if (x % 2 == 1) __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+        if (!(ABL & (ABL_NODMA | ABL_NOWAIT))) {                                                                   \
+            if (R + 4 < nR) wait_vmcnt<2 * PPW>(); else if (R + 3 < nR) wait_vmcnt<PPW>(); else wait_vmcnt<0>();    \
+        }                                                                                                          \
+        if (!(ABL & ABL_NOBAR)) __builtin_amdgcn_s_barrier();                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    } while (0)
+
+    for (int rr = 0; rr < nR; rr += 2) {
+        STEP(rr, 0);
+        STEP(rr + 1, 1);
+    }
+    const long long t2 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // plain epilogue: bf16 stores straight from the accumulator layout (col = l & 15, row = 4 * (l >> 4) + r)
+    bf16_t* C = p.C;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = m0 + wm * WTM + i * 16 + 4 * (lane >> 4) + r;
+                const int col = n0 + wn * WTN + j * 16 + (lane & 15);
+                C[row * p.N + col] = (bf16_t)acc[i][j][r];
+            }
+    if (lane == 0 && p.stamps) {
+        long long* o = p.stamps + ((long)blockIdx.x * NW + wave) * 4;
+        o[0] = t1 - t0; o[1] = t2 - t1; o[2] = __builtin_amdgcn_s_memtime() - t2; o[3] = 0;
+    }
+#undef STEP
+#undef MMA
+#undef READ_B
+#undef READ_A
+}
+
+__global__ void ref_kernel(const bf16_t* A, const bf16_t* W, float* out, const int* rows, int nrows, int N, int K) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * N) return;
+    const int r = rows[idx / N], c = idx % N;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += (float)A[(long)r * K + k] * (float)W[(long)c * K + k];
+    out[idx] = s;
+}
+
+__global__ void fill_kernel(bf16_t* x, long n, uint32_t seed, float scale, int zero) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    uint32_t g = h * 1664525u + 1013904223u;
+    // sum of two uniforms, centred: roughly bell shaped in (-1, 1), full sign and exponent variety
+    float v = ((h >> 8) * (1.0f / 16777216.0f) + (g >> 8) * (1.0f / 16777216.0f) - 1.0f) * scale;
+    x[i] = zero ? (bf16_t)0.0f : (bf16_t)v;
+}
+
+template <int WAVES_N, int ABL, int WAVES_M = 2>
+static void launch(const Params& p, hipStream_t st) {
+    constexpr int smem = 4 * 32768;
+    static bool set = false;
+    if (!set) { CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ring_kernel<WAVES_N, ABL, WAVES_M>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); set = true; }
+    const int grid = (p.M / 256) * (p.N / 256);
+    hipLaunchKernelGGL((ring_kernel<WAVES_N, ABL, WAVES_M>), dim3(grid), dim3(64 * WAVES_M * WAVES_N), smem, st, p);
+}
+
+typedef void (*launch_fn)(const Params&, hipStream_t);
+struct Variant { const char* name; launch_fn fn; int nw; bool exact; };
+
+int main(int argc, char** argv) {
+    int M = 65536, N = 2048, K = 2048, iters = 20, zero = 0;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "-M")) M = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-N")) N = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-K")) K = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-i")) iters = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-z")) zero = 1;
+    }
+    if (M % 256 || N % 256 || K % 64) { fprintf(stderr, "M, N multiples of 256, K of 64\n"); return 1; }
+    bf16_t *A, *W, *C;
+    CHECK(hipMalloc(&A, (size_t)M * K * 2)); CHECK(hipMalloc(&W, (size_t)N * K * 2)); CHECK(hipMalloc(&C, (size_t)M * N * 2));
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long)M * K + 255) / 256)), dim3(256), 0, 0, A, (long)M * K, 1u, 1.0f, zero);
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, 0, W, (long)N * K, 2u, 0.05f, zero);
+    const int grid = (M / 256) * (N / 256);
+    long long* stamps;
+    CHECK(hipMalloc(&stamps, (size_t)grid * 16 * 4 * 8));
+    // reference on sampled rows
+    const int nrows = 64;
+    std::vector<int> hrows(nrows);
+    for (int i = 0; i < nrows; ++i) hrows[i] = (int)(((long)i * 2654435761u) % (unsigned)M);
+    hrows[0] = 0; hrows[1] = M - 1; hrows[2] = 255; hrows[3] = 256;
+    int* drows; float* dref;
+    CHECK(hipMalloc(&drows, nrows * 4)); CHECK(hipMalloc(&dref, (size_t)nrows * N * 4));
+    CHECK(hipMemcpy(drows, hrows.data(), nrows * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ref_kernel, dim3((nrows * N + 255) / 256), dim3(256), 0, 0, A, W, dref, drows, nrows, N, K);
+    std::vector<float> href((size_t)nrows * N);
+    CHECK(hipMemcpy(href.data(), dref, href.size() * 4, hipMemcpyDeviceToHost));
+
+    Variant vs[] = {
+        {"ring4 (4 waves 128x128)", launch<2, 0>, 4, true},
+        {"ring8 (8 waves 128x64)", launch<4, 0>, 8, true},
+        {"ring16 (16 waves 64x64)", launch<4, 0, 4>, 16, true},
+        {"ring16 no-dma", launch<4, ABL_NODMA, 4>, 16, false},
+        {"ring16 no-read", launch<4, ABL_NOREAD, 4>, 16, false},
+        {"ring8 no-read", launch<4, ABL_NOREAD>, 8, false},
+        {"ring8 no-dma", launch<4, ABL_NODMA>, 8, false},
+        {"ring8 no-read no-dma", launch<4, ABL_NOREAD | ABL_NODMA>, 8, false},
+        {"ring8 no-read no-dma no-barrier", launch<4, ABL_NOREAD | ABL_NODMA | ABL_NOBAR>, 8, false},
+        {"ring8 staggered DMA slots", launch<4, ABL_STAGGER>, 8, true},
+        {"ring8 staggered DMA slots (partners adjacent)", launch<4, ABL_STAGGER2>, 8, true},
+        {"ring8 no-wait (vmcnt never awaited)", launch<4, ABL_NOWAIT>, 8, false},
+        {"ring8 same-k (every region from k 0)", launch<4, ABL_SAMEK>, 8, false},
+        {"ring8 same-tile (all WGs tile 0,0)", launch<4, ABL_SAMETILE>, 8, false},
+        {"ring8 same-tile same-k", launch<4, ABL_SAMETILE | ABL_SAMEK>, 8, false},
+        {"ring8 same-tile same-k no-wait", launch<4, ABL_SAMETILE | ABL_SAMEK | ABL_NOWAIT>, 8, false},
+    };
+    Params p{A, W, C, M, N, K, N / 256, stamps};
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const double fl = 2.0 * M * N * K;
+    std::vector<bf16_t> hc((size_t)N);
+    for (const Variant& v : vs) {
+        CHECK(hipMemset(C, 0, (size_t)M * N * 2));
+        for (int i = 0; i < 3; ++i) v.fn(p, 0);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) v.fn(p, 0);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / iters;
+        std::vector<long long> hs((size_t)grid * v.nw * 4);
+        CHECK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+        double pro = 0, mainl = 0, epi = 0;
+        for (size_t i = 0; i < hs.size(); i += 4) { pro += hs[i]; mainl += hs[i + 1]; epi += hs[i + 2]; }
+        const double n = (double)grid * v.nw;
+        double maxerr = 0;
+        if (v.exact) {
+            for (int i = 0; i < nrows; ++i) {
+                CHECK(hipMemcpy(hc.data(), C + (size_t)hrows[i] * N, (size_t)N * 2, hipMemcpyDeviceToHost));
+                for (int c = 0; c < N; ++c) {
+                    const double d = fabs((double)(float)hc[c] - href[(size_t)i * N + c]);
+                    const double tol = 0.01 * fabs(href[(size_t)i * N + c]) + 0.02;
+                    if (!(d / tol <= maxerr)) maxerr = d == d ? d / tol : 1e30;
+                }
+            }
+        }
+        printf("%-36s %8.1f us %7.1f TF | cycles/wave: prologue %6.0f main %7.0f (%5.0f per 64-K) epilogue %6.0f | err/tol %.2f %s\n", v.name, us,
+               fl / us / 1e6, pro / n, mainl / n, mainl / n / (K / 64), epi / n, maxerr, v.exact ? (maxerr <= 1.0 ? "OK" : "MISMATCH") : "");
+        fflush(stdout);
+    }
+    return 0;
+}

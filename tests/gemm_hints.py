@@ -8,7 +8,7 @@ import adcdiff
 from adcdiff import ops
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-hints = [int(h) for h in sys.argv[2].split(",")] if len(sys.argv) > 2 else [128, 256, 2562]
+hints = [int(h) for h in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2560, 2561]
 zeros = len(sys.argv) > 3 and sys.argv[3] == "zeros"   # zero operands: shows how much of the time is the clock the chip holds on real data
 shapes = [(256, [512], 1), (256, [256, 512], 3), (512, [256], 1), (512, [512, 256], 3), (1024, [512], 1), (1024, [1024, 512], 3),
           (2048, [1024], 1), (2048, [2048, 1024], 3), (2048, [2048], 1), (2048, [2048], 2), (1024, [2048, 2048], 1),
