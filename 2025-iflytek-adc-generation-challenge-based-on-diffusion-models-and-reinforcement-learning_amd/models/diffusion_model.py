@@ -17,7 +17,16 @@ Deliberate differences from the reference, all of them places where the referenc
   the seed of each call is drawn from torch's CPU generator, so ``torch.manual_seed`` still makes
   runs reproducible;
 * sampling runs the denoiser in eval mode (dropout off): the reference never calls ``.eval()`` and
-  therefore samples with dropout active, which no parity test could pin.
+  therefore samples with dropout active, which no parity test could pin.  ``p_losses`` follows
+  ``self.model.training`` with and without gradients: a validation loss taken under ``no_grad`` right after
+  ``train_step`` (which leaves the model in train mode, main.py:646-649) has dropout on, as in the reference;
+* supported widths: ``input_dim``, ``hidden_dim`` and ``output_dim`` multiples of 64 with ``input_dim ==
+  output_dim`` (the reverse loop feeds the output back as the input, :299, :702); training additionally
+  needs ``hidden_dim`` a multiple of 128 and a power of two up to 1024 or a multiple of 1024.  Other
+  widths raise ``ValueError`` at construction (``strict_shapes=False`` in the config builds the parameter
+  containers anyway, e.g. to read or write a checkpoint);
+* data-parallel training draws the timesteps of the GLOBAL batch on every rank and keeps its own slice, and keys
+  the forward-diffusion noise by global row, so ranks seeded alike still train on independent samples.
 """
 import ctypes as C
 import gc
@@ -49,6 +58,27 @@ def get_num_groups(dim):
 def _seed_from_torch():
     """A 62-bit seed drawn from torch's CPU generator (so torch.manual_seed controls sampling)."""
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def check_supported_dims(input_dim, hidden_dim, output_dim):
+    """The widths the HIP kernels take (MFMA tiles of 64 columns, GroupNorm groups that divide them); raises ValueError."""
+    bad = [n for n, v in (("input_dim", input_dim), ("hidden_dim", hidden_dim), ("output_dim", output_dim))
+           if not isinstance(v, int) or v <= 0 or v % 64 != 0]
+    if bad:
+        raise ValueError("adcdiff supports input_dim / hidden_dim / output_dim that are positive multiples of 64; got "
+                         "input_dim=%r hidden_dim=%r output_dim=%r (%s). Pad the feature width to a multiple of 64, or pass "
+                         "strict_shapes=False to build the parameter containers only." % (input_dim, hidden_dim, output_dim, ", ".join(bad)))
+    if input_dim != output_dim:
+        raise ValueError("adcdiff needs input_dim == output_dim (got %d and %d): the reverse loop feeds the [B, output_dim] "
+                         "latent back as the [B, input_dim] input and the loss compares them element-wise" % (input_dim, output_dim))
+
+
+def _dp_rank_world():
+    """(rank, world size) of the default process group, (0, 1) without one."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
 
 
 class TimeEmbedding(nn.Module):
@@ -137,6 +167,7 @@ class _Engine:
         self.key = None
         self.version = None
         self.freq = None
+        self.generation = 0     # bumped by every call that (re)uses the workspace: a taped forward is valid for one generation
 
     def _param_key(self):
         return tuple(p.data_ptr() for p in self.model.parameters())
@@ -207,6 +238,7 @@ class _Engine:
         if self.workspace is None or self.workspace.numel() < need or self.workspace.device != device:
             self.workspace = None
             self.workspace = torch.empty(need, device=device, dtype=torch.uint8)
+        self.generation += 1
         return C.c_void_p(self.workspace.data_ptr()), self.workspace.numel()
 
     def workspace_for(self, batch, device):
@@ -217,6 +249,7 @@ class _Engine:
         if self.workspace is None or self.workspace.numel() < need or self.workspace.device != device:
             self.workspace = None
             self.workspace = torch.empty(need, device=device, dtype=torch.uint8)
+        self.generation += 1
         return C.c_void_p(self.workspace.data_ptr()), self.workspace.numel()
 
 
@@ -236,27 +269,39 @@ def _grad_slots(model):
     return slots
 
 
+def _taped_forward_loss(model, x_noisy, t, noise, dropout_p, dropout_seed):
+    """Training-mode denoiser forward (dropout from the counter RNG) + mse_loss(noise, prediction) in the HIP library.
+    Returns (loss, d_eps, engine, handle, workspace tensor, generation): the activations the backward pass needs stay
+    in the engine's workspace until the next call that uses it (which bumps the generation)."""
+    dev = model._device()
+    eng = model.engine()
+    handle = eng.ensure(dev)
+    B = x_noisy.shape[0]
+    ws, ws_bytes = eng.train_workspace_for(B, dev)
+    eps = torch.empty((B, model.output_dim), device=dev, dtype=torch.float32)
+    check(eng.lib.adcdiff_unet_train_forward(handle, ops._ptr(x_noisy), x_noisy.stride(0), B, ops._ptr(t), float(dropout_p),
+                                             int(dropout_seed), ops._ptr(eps), model.output_dim, ws, ws_bytes, ops._stream()))
+    loss = torch.zeros((), device=dev, dtype=torch.float32)
+    d_eps = torch.empty_like(eps)
+    check(eng.lib.adcdiff_mse_loss_grad(ops._ptr(eps), model.output_dim, ops._ptr(noise), noise.stride(0), ops._ptr(d_eps),
+                                        model.output_dim, B, model.output_dim, 1.0, ops._ptr(loss), ops._stream()))
+    return loss, d_eps, eng, handle, eng.workspace, eng.generation
+
+
 class _NoisePredictionLoss(torch.autograd.Function):
     """mse_loss(noise, UNet(x_noisy, t)) with the denoiser's forward AND backward in the HIP library
     (adcdiff_unet_train_forward / adcdiff_mse_loss_grad / adcdiff_unet_backward).  The parameters enter as inputs
-    only so that autograd routes the library's gradients to them."""
+    only so that autograd routes the library's gradients to them.  The taped activations live in the engine's single
+    workspace: backward raises if anything else has used the engine since this forward (a second p_losses, a sample(),
+    a forward()), instead of differentiating through the wrong activations."""
 
     @staticmethod
     def forward(ctx, model, x_noisy, t, noise, dropout_p, dropout_seed, *params):
-        dev = model._device()
-        eng = model.engine()
-        handle = eng.ensure(dev)
-        B = x_noisy.shape[0]
-        ws, ws_bytes = eng.train_workspace_for(B, dev)
-        eps = torch.empty((B, model.output_dim), device=dev, dtype=torch.float32)
-        check(eng.lib.adcdiff_unet_train_forward(handle, ops._ptr(x_noisy), x_noisy.stride(0), B, ops._ptr(t), float(dropout_p),
-                                                 int(dropout_seed), ops._ptr(eps), model.output_dim, ws, ws_bytes, ops._stream()))
-        loss = torch.zeros((), device=dev, dtype=torch.float32)
-        d_eps = torch.empty_like(eps)
-        check(eng.lib.adcdiff_mse_loss_grad(ops._ptr(eps), model.output_dim, ops._ptr(noise), noise.stride(0), ops._ptr(d_eps),
-                                            model.output_dim, B, model.output_dim, 1.0, ops._ptr(loss), ops._stream()))
+        loss, d_eps, eng, handle, ws_tensor, generation = _taped_forward_loss(model, x_noisy, t, noise, dropout_p, dropout_seed)
         ctx.model, ctx.eng, ctx.handle, ctx.d_eps, ctx.t = model, eng, handle, d_eps, t
-        ctx.ws = (ws, ws_bytes)
+        ctx.inputs = (x_noisy, t, noise)     # the tape points at x_noisy and t: they must outlive the forward call
+        ctx.ws_tensor = ws_tensor            # keeps the buffer alive even if the engine re-allocates a larger one
+        ctx.generation = generation
         ctx.version = eng._param_version()
         return loss
 
@@ -265,31 +310,51 @@ class _NoisePredictionLoss(torch.autograd.Function):
         model, eng = ctx.model, ctx.eng
         if eng._param_version() != ctx.version or eng.handle is None or eng.handle.value != ctx.handle.value:
             raise AdcdiffError("parameters changed between the training forward and backward")
+        if eng.generation != ctx.generation or eng.workspace is not ctx.ws_tensor:
+            raise AdcdiffError("the denoiser's workspace was used again (another p_losses / sample / forward call) between this "
+                               "loss's forward and its backward: the taped activations are gone. Call backward() on each loss "
+                               "before the next call into the model.")
         params = list(model.parameters())
         slots = _grad_slots(model)
-        total = sum(p.numel() for p, _ in slots)
-        flat = torch.zeros(total + 4 * len(slots), device=ctx.d_eps.device, dtype=torch.float32)
+        flat, views = model._grad_arena(slots)
+        # gradient accumulation: gradients of an earlier micro-step that still live in the arena move to a buffer of their own
+        if any(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for (p, _), v in zip(slots, views)):
+            keep = flat.clone()
+            off = 0
+            for (p, _), v in zip(slots, views):
+                if p.grad is not None and p.grad.data_ptr() == v.data_ptr():
+                    p.grad = keep[off:off + p.numel()].view_as(p)
+                off += (p.numel() + 3) // 4 * 4
+        flat.zero_()                         # bias / GroupNorm gradients are accumulated with atomics
         grads = _lib.UnetGrads()
         by_param = {}
-        off = 0
-        for p, path in slots:
-            g = flat[off:off + p.numel()].view_as(p)
-            off += (p.numel() + 3) // 4 * 4      # keep every gradient 16-byte aligned
+        for (p, path), g in zip(slots, views):
             by_param[id(p)] = g
             target = grads if len(path) == 1 else grads.blocks[path[0]]
             setattr(target, path[-1], g.data_ptr())
-        ws, ws_bytes = ctx.ws
-        check(eng.lib.adcdiff_unet_backward(ctx.handle, ops._ptr(ctx.d_eps), model.output_dim, C.byref(grads), ws, ws_bytes, ops._stream()))
-        flat.mul_(grad_out)
-        return (None, None, None, None, None, None) + tuple(by_param.get(id(p)) for p in params)
+        ws = C.c_void_p(ctx.ws_tensor.data_ptr())
+        check(eng.lib.adcdiff_unet_backward(ctx.handle, ops._ptr(ctx.d_eps), model.output_dim, C.byref(grads), ws, ctx.ws_tensor.numel(),
+                                            ops._stream()))
+        eng.generation += 1                  # the tape is consumed
+        flat.mul_(grad_out)                  # d(loss * c) = c * d(loss): one pass over the arena, no host sync
+        out = []
+        for p in params:
+            g = by_param.get(id(p))
+            if g is not None and p.grad is None and p.requires_grad:
+                p.grad = g                   # the arena view IS the gradient: nothing is allocated or copied per step
+                g = None
+            out.append(g)
+        return (None, None, None, None, None, None) + tuple(out)
 
 
 class UNetModel(nn.Module):
     """The reference's MLP "U-Net" noise predictor (diffusion_model.py:677-789) on the HIP library."""
 
     def __init__(self, input_dim: int, hidden_dim: int, output_dim: int, num_timesteps: int,
-                 enable_memory_efficient_attention: bool = True, compute_dtype: str = "bf16"):
+                 enable_memory_efficient_attention: bool = True, compute_dtype: str = "bf16", strict_shapes: bool = True):
         super().__init__()
+        if strict_shapes:
+            check_supported_dims(input_dim, hidden_dim, output_dim)
         self.input_dim = input_dim
         self.hidden_dim = hidden_dim
         self.output_dim = output_dim
@@ -320,6 +385,43 @@ class UNetModel(nn.Module):
         self.output_layer = nn.Linear(hidden_dim, output_dim)
         self._initialize_weights()
         self._engines = {}
+        self._grad_flat = None
+
+    def _grad_arena(self, slots):
+        """One persistent flat float32 buffer with a 16-byte aligned view per parameter gradient (allocated once)."""
+        dev = self._device()
+        total = sum((p.numel() + 3) // 4 * 4 for p, _ in slots)
+        if self._grad_flat is None or self._grad_flat[0].numel() != total or self._grad_flat[0].device != dev:
+            flat = torch.empty(total, device=dev, dtype=torch.float32)
+            views, off = [], 0
+            for p, _ in slots:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += (p.numel() + 3) // 4 * 4
+            self._grad_flat = (flat, views)
+        return self._grad_flat
+
+    def grad_arena_if_aliased(self):
+        """The flat gradient buffer when every existing .grad is a view of it (one in-place all-reduce then averages them all)."""
+        if self._grad_flat is None:
+            return None
+        flat, views = self._grad_flat
+        ptrs = {v.data_ptr() for v in views}
+        have = [p for p in self.parameters() if p.grad is not None]
+        if have and all(p.grad.data_ptr() in ptrs for p in have) and len(have) == len(views):
+            return flat
+        return None
+
+    def expand_condition(self, condition, batch):
+        """[input_dim] or [1, input_dim] -> one row (broadcast later), [batch, input_dim] as is; anything else raises, as the
+        reference's t_emb + c_emb broadcast would (diffusion_model.py:766)."""
+        if condition.dim() == 1:
+            condition = condition.unsqueeze(0)
+        if condition.dim() != 2 or condition.shape[1] != self.input_dim:
+            raise ValueError("condition must be [B, %d], [1, %d] or [%d]; got %s" % (self.input_dim, self.input_dim, self.input_dim,
+                                                                                     tuple(condition.shape)))
+        if condition.shape[0] not in (1, batch):
+            raise ValueError("condition has %d rows for a batch of %d (1 or %d expected)" % (condition.shape[0], batch, batch))
+        return condition
 
     def _initialize_weights(self):
         """xavier_uniform_ weights, zero biases, GroupNorm weight 1 / bias 0 (diffusion_model.py:738-747)."""
@@ -345,17 +447,23 @@ class UNetModel(nn.Module):
             raise AdcdiffError("the denoiser runs on an MI355X only (parameters are on %s); no CPU fallback exists" % dev)
         return dev
 
-    def condition_embedding(self, condition, compute_dtype=None):
-        """condition_embed(condition) (diffusion_model.py:694-698, 765): computed once per sampling call."""
+    def condition_embedding(self, condition, compute_dtype=None, batch=None):
+        """condition_embed(condition) (diffusion_model.py:694-698, 765): computed once per sampling call.  With `batch`
+        the condition is checked against it and a one-row condition's embedding is repeated to [batch, hidden] (rows of
+        the embedding do not depend on each other, so this equals embedding the repeated condition)."""
         dev = self._device()
         eng = self.engine(compute_dtype)
         handle = eng.ensure(dev)
+        if batch is not None:
+            condition = self.expand_condition(condition, batch)
         cond = condition.to(device=dev, dtype=torch.float32).contiguous()
         B = cond.shape[0]
         ws, ws_bytes = eng.workspace_for(B, dev)
         cemb = torch.empty((B, self.hidden_dim), device=dev, dtype=torch.float32)
         check(eng.lib.adcdiff_unet_condition_embed(handle, ops._ptr(cond), cond.stride(0), B, ops._ptr(cemb), self.hidden_dim, ws,
                                                    ws_bytes, ops._stream()))
+        if batch is not None and B == 1 and batch > 1:
+            cemb = cemb.expand(batch, -1).contiguous()
         return cemb
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -369,7 +477,7 @@ class UNetModel(nn.Module):
         B = x.shape[0]
         if x.shape[1] != self.input_dim or t.shape[0] != B:
             raise ValueError("x must be [B, %d] and t [B]" % self.input_dim)
-        cemb = self.condition_embedding(condition) if condition is not None else None
+        cemb = self.condition_embedding(condition, batch=B) if condition is not None else None
         ws, ws_bytes = eng.workspace_for(B, dev)
         eps = torch.empty((B, self.output_dim), device=dev, dtype=torch.float32)
         check(eng.lib.adcdiff_unet_forward(handle, ops._ptr(x), x.stride(0), B, ops._ptr(t), 0, ops._ptr(cemb), self.hidden_dim,
@@ -408,6 +516,7 @@ class DiffusionModel(nn.Module):
             num_timesteps=self.num_timesteps,
             enable_memory_efficient_attention=self.enable_memory_efficient_attention,
             compute_dtype=self.compute_dtype,
+            strict_shapes=config.get('strict_shapes', True),
         ).to(self.device)
 
         # schedule tables: computed on the host with the reference's own expressions (:57-60), then moved
@@ -509,22 +618,27 @@ class DiffusionModel(nn.Module):
                             noise=noise.contiguous() if noise is not None else None, seed=seed)
 
     def p_losses(self, x_start: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None,
-                 noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 noise: Optional[torch.Tensor] = None, row_offset: int = 0) -> torch.Tensor:
         """diffusion_model.py:165-184.  With gradients enabled the returned loss back-propagates through the HIP
-        backward kernels (unconditional, as in the reference's train_step); otherwise only the value is computed."""
+        backward kernels (unconditional, as in the reference's train_step).  Dropout follows self.model.training with and
+        without gradients.  row_offset keys the counter-RNG noise by global row (data-parallel training)."""
         dv = self._device_tables()
         x_noisy, used = ops.q_sample(x_start.to(torch.float32).contiguous(), t.to(torch.int64).contiguous(), dv["sqrt_ac"],
                                      dv["sqrt_1mac"], noise=noise.contiguous() if noise is not None else None,
-                                     seed=_seed_from_torch() if noise is None else 0, return_noise=True)
+                                     seed=_seed_from_torch() if noise is None else 0, row_offset=row_offset, return_noise=True)
         wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters())
-        if not wants_grad:
+        drop_p = self.model.encoder[0].dropout.p if self.model.training else 0.0
+        if not wants_grad and (condition is not None or drop_p == 0.0):
             predicted_noise = self.model(x_noisy, t, condition)
             return F.mse_loss(used, predicted_noise)
         if condition is not None:
             raise NotImplementedError("the backward kernels cover the unconditional loss of train_step; a condition has no gradient path yet")
-        drop_p = self.model.encoder[0].dropout.p if self.model.training else 0.0
-        return _NoisePredictionLoss.apply(self.model, x_noisy, t.to(torch.int64).contiguous(), used, drop_p,
-                                          _seed_from_torch() if drop_p > 0 else 0, *self.model.parameters())
+        rank, _ = _dp_rank_world()
+        drop_seed = (_seed_from_torch() + rank) if drop_p > 0 else 0     # ranks seeded alike still draw different masks
+        t64 = t.to(torch.int64).contiguous()
+        if not wants_grad:   # value only, train mode: the taped forward with dropout, no backward
+            return _taped_forward_loss(self.model, x_noisy, t64, used, drop_p, drop_seed)[0]
+        return _NoisePredictionLoss.apply(self.model, x_noisy, t64, used, drop_p, drop_seed, *self.model.parameters())
 
     # ---- reverse process --------------------------------------------------------------------
     def p_sample(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None,
@@ -547,7 +661,7 @@ class DiffusionModel(nn.Module):
         handle = eng.ensure(dev)
         cemb = None
         if condition is not None:
-            cemb = self.model.condition_embedding(condition.to(dev), self.compute_dtype)
+            cemb = self.model.condition_embedding(condition.to(dev), self.compute_dtype, batch=batch)
         ws, ws_bytes = eng.workspace_for(batch, dev)
         return dev, eng, handle, cemb, ws, ws_bytes
 
@@ -665,15 +779,18 @@ class DiffusionModel(nn.Module):
         if batch_size > self.max_batch_size:
             return self._train_step_chunked(x, step)
         x = x.to(self.device)
-        t = torch.randint(0, self.num_timesteps, (batch_size,), device=self.device)
-        loss = self.p_losses(x, t)
+        rank, world = _dp_rank_world()
+        # data parallel: every rank draws the timesteps of the global batch and keeps its own slice, and the forward-diffusion
+        # noise is keyed by global row, so ranks seeded alike train on independent samples (one process: the plain draw)
+        t = torch.randint(0, self.num_timesteps, (world * batch_size,), device=self.device)[rank * batch_size:(rank + 1) * batch_size]
+        loss = self.p_losses(x, t, row_offset=rank * batch_size)
         loss = loss / self.gradient_accumulation_steps
         loss.backward()
         if (step + 1) % self.gradient_accumulation_steps == 0:
             # data parallel (one process per GPU): average the gradients over the ranks before clipping, so that the
             # clipped norm and the AdamW step are identical on every rank; a no-op in a single process
             from ..parallel import allreduce_gradients
-            allreduce_gradients(self.model.parameters())
+            allreduce_gradients(self.model.parameters(), flat=self.model.grad_arena_if_aliased())
             if self._fused_opt is None or self._fused_opt.optimizer is not self.optimizer:
                 from ..optim import FusedClipAdamW
                 self._fused_opt = FusedClipAdamW(self.optimizer, max_norm=1.0)

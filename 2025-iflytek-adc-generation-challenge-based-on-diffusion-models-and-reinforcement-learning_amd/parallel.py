@@ -80,8 +80,11 @@ def sample_ddpm_sharded(model, total: int, condition: Optional[torch.Tensor] = N
     return sample_sharded(run, total, group)
 
 
-def allreduce_gradients(parameters, group=None, bucket_bytes: int = 256 << 20) -> None:
+def allreduce_gradients(parameters, group=None, bucket_bytes: int = 256 << 20, flat: Optional[torch.Tensor] = None) -> None:
     """Data-parallel gradient averaging: sum the ranks' `.grad` tensors and divide by the world size.
+
+    flat: a buffer that every `.grad` is a view of (UNetModel.grad_arena_if_aliased(): the HIP backward writes all
+    gradients into one arena) -- it is then reduced in place by ONE collective, with no packing or copy-back.
 
     Gradients are packed into flat float32 buckets (default 256 MiB: the whole 44.3 M-parameter denoiser is 177 MB, i.e.
     one all-reduce; xGMI is point-to-point, so few large ring collectives beat many small ones) and reduced with one
@@ -90,6 +93,10 @@ def allreduce_gradients(parameters, group=None, bucket_bytes: int = 256 << 20) -
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     world = dist.get_world_size(group)
+    if flat is not None:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
+        return
     params = [p for p in parameters if p.grad is not None]
     bucket, size = [], 0
     buckets = []

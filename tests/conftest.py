@@ -20,22 +20,45 @@ def load_golden(name):
 
 
 def rel_err(a, b):
-    """max |a-b| / max(1, max|b|): the per-element tolerance measure used by every parity test."""
+    """max |a-b| / max(1, max|b|): error relative to the TENSOR's largest entry (used for single forwards and kernels)."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
 
 
-@pytest.fixture(scope="session")
-def golden_tiny():
-    return load_golden("tiny")
+def elem_err(a, b):
+    """(max, 99.9th percentile) over the elements of |a_ij - b_ij| / max(1, |b_ij|): the PER-ELEMENT measure of the final
+    latents of a reverse loop (an element of magnitude 180 may be off by 180 * gate, not by gate * the tensor's maximum)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    e = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    return float(e.max()), float(np.percentile(e, 99.9))
 
 
-@pytest.fixture(scope="session")
-def golden_a():
-    return load_golden("config_a")
+def row_scaled_err(a, b):
+    """max over elements of |a_ij - b_ij| / max(1, rms_j(b_i)): the error of an element against the scale of its own row."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    rms = np.sqrt((b ** 2).mean(axis=-1, keepdims=True))
+    return float((np.abs(a - b) / np.maximum(1.0, rms)).max())
 
 
-@pytest.fixture(scope="session")
-def golden_b():
-    return load_golden("config_b")
+# Gates on the final latents of a reverse loop, about 3x what was observed on an MI355X for {tiny, Config A, Config B} x
+# {DDPM 1000, DDIM 50} (profiles/parity_r02.json, written by tests/parity_report.py; observed maxima in brackets):
+#   elem_max / elem_p999: |d_ij| / max(1, |ref_ij|)       fp32 [1.9e-4 / 1.2e-4]   bf16 [1.63 / 0.88]
+#   row_scaled:           |d_ij| / max(1, rms of ref row)  fp32 [2.0e-5]            bf16 [1.1e-2]
+# The latents grow to |x| ~ 180 (median) .. 990 (max) with random weights, and the bf16-operand path carries an ABSOLUTE error
+# of up to 2.6 whatever the element's own magnitude, so its per-element relative error is of order one for the elements that
+# happen to lie near zero; the row-scaled measure says what that error is against the scale of the row it sits in.
+LOOP_GATE = {
+    "fp32": dict(elem_max=6e-4, elem_p999=4e-4, row_scaled=6e-5),
+    "bf16": dict(elem_max=5.0, elem_p999=2.7, row_scaled=3.3e-2),
+}
+
+
+def check_loop(out, ref, dtype, what=""):
+    mx, p999 = elem_err(out, ref)
+    rs = row_scaled_err(out, ref)
+    gate = LOOP_GATE[dtype]
+    print("parity %s %s: per-element max %.3e  99.9%% %.3e  row-scaled %.3e" % (what, dtype, mx, p999, rs))
+    assert mx <= gate["elem_max"] and p999 <= gate["elem_p999"] and rs <= gate["row_scaled"], (what, dtype, mx, p999, rs)

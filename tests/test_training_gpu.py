@@ -198,3 +198,182 @@ def test_fused_clip_adamw_matches_torch(opt_cls):
     sd = ob.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
     ob.load_state_dict(sd)
+
+
+def _feed_draws(monkeypatch, t, nz):
+    """Route recorded timesteps and noise through the two places train_step draws them."""
+    real_randint = torch.randint
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: cu(t, torch.int64) if "device" in k else real_randint(*a, **k))
+    real_q = adcdiff.ops.q_sample
+    monkeypatch.setattr(adcdiff.ops, "q_sample", lambda *a, **k: real_q(*a, **{**k, "noise": cu(nz)}))
+
+
+def test_checkpoint_chain_matches_reference(tmp_path, monkeypatch):
+    """train_step -> save_model -> load_model into a fresh model -> forward and a second train_step, against what the
+    reference produced on the same chain through its own save_model / load_model (tests/golden/tiny_ckpt.npz, written by
+    tests/golden/make_checkpoint.py).  The second step's AdamW update uses the restored moments and step count (bias
+    corrections of step 2), so a checkpoint that dropped or reordered optimizer state would show in the weights.
+    Tolerances as for the single step: loss 1e-5 relative; weights 99.5 % within 2e-6 of the reference's, all within 1e-4
+    (two steps of lr = 1e-4 on entries whose gradient is float32 noise)."""
+    g = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "tiny_ckpt.npz"))
+    m = build("fp32", use_mixed_precision=False)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    with monkeypatch.context() as mp_:
+        _feed_draws(mp_, g["step1_t"], philox.normal(SEED, philox.STREAM_QNOISE, 0, 0, 8, 128))
+        res = m.train_step(cu(g["step1_x0"]), 0)
+    assert abs(res["loss"] - float(g["step1_loss"])) < 1e-5 * float(g["step1_loss"])
+    path = str(tmp_path / "ckpt.pth")
+    m.save_model(path)
+    saved = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(saved) == {"model_state_dict", "optimizer_state_dict", "config"}
+    assert len(saved["optimizer_state_dict"]["state"]) == int(g["opt_n_state"])
+    assert float(saved["optimizer_state_dict"]["state"][0]["step"]) == float(g["opt_step"])
+    norm = np.sqrt(sum(float((s["exp_avg"].double() ** 2).sum()) for s in saved["optimizer_state_dict"]["state"].values()))
+    assert abs(norm - float(g["opt_exp_avg_norm"])) < 1e-4 * float(g["opt_exp_avg_norm"])
+
+    fresh = adcdiff.DiffusionModel(dict(input_dim=128, hidden_dim=128, output_dim=128, compute_dtype="fp32", use_mixed_precision=False))
+    for mod in fresh.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    fresh.load_model(path)
+    a, b = fresh.optimizer.state_dict(), saved["optimizer_state_dict"]
+    assert a["param_groups"] == b["param_groups"]
+    for i, st in b["state"].items():
+        for k in ("exp_avg", "exp_avg_sq", "step"):
+            assert torch.equal(a["state"][i][k].cpu(), st[k]), (i, k)
+    for k in ("output_layer.weight", "middle.0.linear1.weight", "encoder.3.residual_proj.bias"):
+        got, ref = golden_tensor(g, "loaded." + k, fresh.model.state_dict()[k])
+        diff = np.abs(got - ref)
+        assert (diff < 2e-6).mean() > 0.995 and diff.max() < 5e-5, k
+    fresh.model.eval()
+    y = fresh.model(cu(philox.normal(SEED, 50, 0, 0, 8, 128)), cu(g["fwd_t"], torch.int64)).cpu().numpy()
+    assert rel_err(y, g["fwd_restored"]) < 1e-4     # forward of weights that differ from the reference's by <= 5e-5
+    with monkeypatch.context() as mp_:
+        _feed_draws(mp_, g["step2_t"], philox.normal(SEED, philox.STREAM_QNOISE, 1, 0, 8, 128))
+        res2 = fresh.train_step(cu(g["step2_x0"]), 1)
+    assert abs(res2["loss"] - float(g["step2_loss"])) < 2e-5 * float(g["step2_loss"])
+    sd = fresh.model.state_dict()
+    for k in ("output_layer.weight", "middle.0.linear1.weight", "encoder.0.norm1.weight", "time_embed.linear1.bias",
+              "decoder.2.time_proj.1.weight", "encoder.3.residual_proj.bias"):
+        got, ref = golden_tensor(g, "step2_after." + k, sd[k])
+        diff = np.abs(got - ref)
+        assert (diff < 4e-6).mean() > 0.99 and diff.max() < 1e-4, (k, float(diff.max()), float((diff < 4e-6).mean()))
+    assert float(fresh.optimizer.state_dict()["state"][0]["step"]) == 2.0
+
+
+def test_stale_training_tape_raises():
+    """The taped activations of a training forward live in the engine's one workspace: using the model again before
+    backward() must raise instead of differentiating through the wrong activations."""
+    from adcdiff._lib import AdcdiffError
+    m = build("fp32")
+    x, t = cu(philox.normal(SEED, 52, 0, 0, 8, 128)), torch.arange(8, device="cuda") * 100
+    l1 = m.p_losses(x, t)
+    l2 = m.p_losses(x[:4], t[:4])
+    with pytest.raises(AdcdiffError, match="workspace was used again"):
+        (l1 + l2).backward()
+    m.model.zero_grad(set_to_none=True)
+    l1 = m.p_losses(x, t)
+    m.sample(4, use_ddim=False, seed=1, t_start=999, t_stop=998)
+    with pytest.raises(AdcdiffError, match="workspace was used again"):
+        l1.backward()
+    m.model.zero_grad(set_to_none=True)
+    l1 = m.p_losses(x, t)
+    big = m.p_losses(cu(philox.normal(SEED, 52, 0, 0, 600, 128)), torch.arange(600, device="cuda"))   # re-allocates the workspace
+    with pytest.raises(AdcdiffError):
+        l1.backward()
+    big.backward()                                   # the latest loss is still differentiable
+    assert all(torch.isfinite(p.grad).all() for p in m.model.parameters() if p.grad is not None)
+    with pytest.raises(RuntimeError):                # AdcdiffError is one; autograd's own "second time" error would do too
+        big.backward()                               # and only once
+
+
+def test_gradient_accumulation_keeps_earlier_gradients():
+    """Two backward passes without zero_grad: the second must add to the first, although both are computed into the same
+    persistent gradient arena (which the first pass's .grad tensors alias)."""
+    m = build("fp32")
+    m.model.eval()
+    x, t = cu(philox.normal(SEED, 52, 0, 0, 16, 128)), torch.arange(16, device="cuda") * 50
+    nz = cu(philox.normal(SEED, 53, 0, 0, 16, 128))
+    m.p_losses(x[:8], t[:8], noise=nz[:8]).backward()
+    flat = m.model.grad_arena_if_aliased()
+    assert flat is not None                          # nothing was copied: the gradients are views of the arena
+    ga = {k: p.grad.clone() for k, p in m.model.named_parameters() if p.grad is not None}
+    m.p_losses(x[8:], t[8:], noise=nz[8:]).backward()
+    assert m.model.grad_arena_if_aliased() is None   # the accumulated gradients moved to a buffer of their own
+    total = {k: p.grad.clone() for k, p in m.model.named_parameters() if p.grad is not None}
+    m.model.zero_grad(set_to_none=True)
+    m.p_losses(x[8:], t[8:], noise=nz[8:]).backward()
+    for k, p in m.model.named_parameters():
+        if p.grad is not None:
+            assert torch.allclose(total[k], ga[k] + p.grad, rtol=0, atol=1e-6 * max(1.0, float(total[k].abs().max()))), k
+
+
+def test_validation_loss_follows_training_mode():
+    """p_losses under no_grad: eval mode gives the dropout-free value; train mode (where train_step leaves the model,
+    as in the reference's validation pass, main.py:646-649) applies dropout, reproducibly for a fixed torch seed."""
+    m = build("fp32")
+    x, t = cu(philox.normal(SEED, 52, 0, 0, 64, 128)), torch.arange(64, device="cuda") * 15
+    nz = cu(philox.normal(SEED, 53, 0, 0, 64, 128))
+    with torch.no_grad():
+        m.model.eval()
+        e1, e2 = float(m.p_losses(x, t, noise=nz)), float(m.p_losses(x, t, noise=nz))
+        m.model.train()
+        torch.manual_seed(11); d1 = float(m.p_losses(x, t, noise=nz))
+        torch.manual_seed(11); d2 = float(m.p_losses(x, t, noise=nz))
+        torch.manual_seed(12); d3 = float(m.p_losses(x, t, noise=nz))
+    assert e1 == e2 and d1 == d2 and d1 != e1 and d3 != d1
+    assert abs(d1 - e1) < 0.2 * e1
+
+
+def _dp_worker(rank, world, port, out_dir):
+    import os
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import load_golden
+        g = load_golden("tiny")
+        m = build("fp32", use_mixed_precision=False)
+        m.model.eval()
+        lo, hi = rank * 4, rank * 4 + 4
+        nz = cu(philox.normal(SEED, philox.STREAM_QNOISE, 0, 0, 8, 128))
+        m.p_losses(cu(g["train_x0"])[lo:hi], cu(g["train_t"], torch.int64)[lo:hi], noise=nz[lo:hi]).backward()
+        from adcdiff.parallel import allreduce_gradients
+        flat = m.model.grad_arena_if_aliased()
+        assert flat is not None
+        allreduce_gradients(m.model.parameters(), flat=flat)
+        np.savez(os.path.join(out_dir, "dp%d.npz" % rank), **{k: p.grad.cpu().numpy() for k, p in m.model.named_parameters() if p.grad is not None})
+        # the timestep draw of train_step: ranks seeded alike keep different slices of one global draw
+        torch.manual_seed(3)
+        import adcdiff.models.diffusion_model as dm
+        r, w = dm._dp_rank_world()
+        t = torch.randint(0, 1000, (w * 4,), device="cuda")[r * 4:(r + 1) * 4]
+        np.save(os.path.join(out_dir, "t%d.npy" % rank), t.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_match_full_batch_reference(golden_tiny, tmp_path):
+    """Two processes (gloo, both on this GPU) each back-propagate one half of the golden batch through the HIP path and
+    average their gradient arenas in place: the result must be the reference's full-batch gradient (tiny.npz), on both ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = golden_tiny
+    a, b = np.load(str(tmp_path / "dp0.npz")), np.load(str(tmp_path / "dp1.npz"))
+    checked = 0
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+        key = "grad." + k
+        if key in g.files or key + ".sample" in g.files:
+            got, ref = golden_tensor(g, key, torch.from_numpy(a[k]))
+            assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6), k
+            checked += 1
+    assert checked >= 14
+    t0, t1 = np.load(str(tmp_path / "t0.npy")), np.load(str(tmp_path / "t1.npy"))
+    assert not np.array_equal(t0, t1)
