@@ -77,7 +77,7 @@ class AdamWArgs(C.Structure):
 
 
 OPT_CHUNK = 4096
-KIND_GEMM_F32, KIND_GEMM_BF16, KIND_GROUPNORM, KIND_UPDATE, KIND_GEMM_BF16_T256 = 0, 1, 2, 3, 4
+KIND_GEMM_F32, KIND_GEMM_BF16, KIND_GROUPNORM, KIND_UPDATE, KIND_GEMM_BF16_T256, KIND_OTHER = 0, 1, 2, 3, 4, 5
 
 # name -> (restype, argtypes): every symbol include/adcdiff.h declares
 SIGNATURES = {

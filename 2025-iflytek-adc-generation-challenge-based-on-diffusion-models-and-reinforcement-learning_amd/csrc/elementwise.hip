@@ -2,10 +2,11 @@
 // variance, Philox noise), DDIM update, q_sample, Philox fill, and the small table helpers.
 // Built with -ffp-contract=off so that the update formulas round exactly like the reference's
 // separate float32 torch ops.
-#include <algorithm>
 #include <cmath>
 
 #include "common.h"
+
+#define TRY_RC(expr) do { int rc_ = (expr); if (rc_ != ADCDIFF_OK) return rc_; } while (0)
 
 namespace adcdiff {
 
@@ -23,13 +24,15 @@ int fail(int code, const char* fmt, ...) {
 }
 
 // ------------------------------------------------------------------ per-launch timing
+// One event in FRONT of every recorded launch and one behind the last: a launch's time is the span to the next
+// launch's event, so the records of a window add up to the window (dispatch gaps are charged to the launch in front of them).
 namespace {
 struct TimingState {
     bool on = false;
     int cap = 0, used = 0;
-    hipEvent_t* ev = nullptr;            // 2 * cap events
+    hipEvent_t* ev = nullptr;            // cap + 1 events
     adcdiff_timing_record* rec = nullptr;
-    hipStream_t last_stream = nullptr;   // where the empty event pairs of the calibration are recorded
+    hipStream_t last_stream = nullptr;   // where the closing event is recorded
 } g_timing;
 }  // namespace
 
@@ -38,12 +41,10 @@ TimingScope::TimingScope(int kind, int M, int N, int K, double flops, double byt
     slot = g_timing.used++;
     g_timing.rec[slot] = adcdiff_timing_record{kind, M, N, K, 0.0f, flops, bytes};
     g_timing.last_stream = stream;
-    (void)hipEventRecord(g_timing.ev[2 * slot], stream);
+    (void)hipEventRecord(g_timing.ev[slot], stream);
 }
 
-TimingScope::~TimingScope() {
-    if (slot >= 0) (void)hipEventRecord(g_timing.ev[2 * slot + 1], stream);
-}
+TimingScope::~TimingScope() {}
 
 // ------------------------------------------------------------------ GroupNorm + SiLU
 // One float4 (four channels) per thread; a group of gs channels spans gs/4 adjacent lanes, so the two
@@ -303,6 +304,7 @@ int sinusoid_table(float* out, int ld, int rows, int half, const float* freq, hi
 
 int temb_silu(const float* te_table, int ldt, int table_rows, const int64_t* t_rows, int t_uniform, const float* cemb, int ldce, int dtype,
               void* out, int ldo, int rows, int H, hipStream_t stream) {
+    TimingScope ts(ADCDIFF_KIND_OTHER, rows, H, 0, 0.0, (double)rows * H * (dtype == ADCDIFF_BF16 ? 6.0 : 8.0), stream);
     const long total = (long)rows * H;
     const dim3 grid((unsigned)((total + 255) / 256));
     if (dtype == ADCDIFF_BF16)
@@ -315,6 +317,7 @@ int temb_silu(const float* te_table, int ldt, int table_rows, const int64_t* t_r
 }
 
 int cast_pack(const float* src, int lds_, int dtype, void* dst, int ldd, int col0, int rows, int cols, hipStream_t stream) {
+    TimingScope ts(ADCDIFF_KIND_OTHER, rows, cols, 0, 0.0, (double)rows * cols * (dtype == ADCDIFF_BF16 ? 6.0 : 8.0), stream);
     const long total = (long)rows * cols;
     const dim3 grid((unsigned)((total + 255) / 256));
     if (dtype == ADCDIFF_BF16)
@@ -349,6 +352,7 @@ extern "C" int adcdiff_philox_normal(float* out, int ld, int rows, int cols, uin
     if (rows <= 0 || cols <= 0 || cols % 4 != 0 || !rowvec_ok(out, ld, cols))
         return fail(ADCDIFF_E_BADARG, "philox_normal: rows=%d cols=%d (multiple of 4) ld=%d", rows, cols, ld);
     const long total4 = (long)rows * (cols / 4);
+    TimingScope ts(ADCDIFF_KIND_OTHER, rows, cols, 0, 0.0, (double)rows * cols * 4.0, as_stream(stream));
     hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream), out, ld, total4,
                        cols / 4, seed, stream_id, step, row_offset);
     return check_launch("philox_normal");
@@ -380,6 +384,7 @@ extern "C" int adcdiff_ddim_step(const float* x, int ldx, const float* eps, int 
         return fail(ADCDIFF_E_BADARG, "ddim_step: B=%d D=%d (multiple of 4), pointers 16-byte aligned, ld >= D", B, D);
     const long total4 = (long)B * (D / 4);
     const dim3 grid((unsigned)((total4 + 255) / 256));
+    TimingScope ts(ADCDIFF_KIND_UPDATE, B, D, 0, 0.0, (double)B * D * (noise ? 16.0 : 12.0), as_stream(stream));
     if (noise)
         hipLaunchKernelGGL((ddim_step_kernel<true>), grid, dim3(256), 0, as_stream(stream), x, ldx, eps, lde, noise, ldn, out, ldo,
                            total4, D / 4, coef, seed, step, row_offset);
@@ -397,6 +402,7 @@ extern "C" int adcdiff_q_sample(const float* x0, int ldx, const int64_t* t, cons
         return fail(ADCDIFF_E_BADARG, "q_sample: B=%d D=%d (multiple of 4), pointers 16-byte aligned, ld >= D", B, D);
     const long total4 = (long)B * (D / 4);
     const dim3 grid((unsigned)((total4 + 255) / 256));
+    TimingScope ts(ADCDIFF_KIND_OTHER, B, D, 0, 0.0, (double)B * D * ((noise ? 12.0 : 8.0) + (noise_out ? 4.0 : 0.0)), as_stream(stream));
     if (noise)
         hipLaunchKernelGGL((q_sample_kernel<true>), grid, dim3(256), 0, as_stream(stream), x0, ldx, t, sqrt_ac, sqrt_one_minus_ac,
                            noise, ldn, out, ldo, noise_out, ldno, total4, D / 4, seed, step, row_offset, num_timesteps);
@@ -459,6 +465,7 @@ extern "C" int adcdiff_latent_summary(const float* x, int ldx, int B, int D, flo
     if (!x || !out || B <= 0 || ldx < D || ld_out < 5) return fail(ADCDIFF_E_BADARG, "latent_summary: null pointers, B=%d, ldx=%d < D or ld_out=%d < 5", B, ldx, ld_out);
     if (D < 128 || D > 4096 || (D & (D - 1)) != 0)
         return fail(ADCDIFF_E_BADARG, "latent_summary: D=%d; numpy's pairwise order is reproduced for D = 128 * 2^k up to 4096", D);
+    TimingScope ts(ADCDIFF_KIND_OTHER, B, D, 0, 0.0, (double)B * (D * 4.0 + 20.0), as_stream(stream_));
     hipLaunchKernelGGL(latent_summary_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream_), x, (long)ldx, B, D, out, (long)ld_out);
     return check_launch("latent_summary");
 }
@@ -578,19 +585,13 @@ extern "C" size_t adcdiff_clip_adamw_workspace_bytes(long long total_chunks) {
     return total_chunks <= 0 ? 0 : (size_t)total_chunks * 4 + 256;
 }
 
-extern "C" int adcdiff_clip_adamw_step(const adcdiff_opt_tensor* tensors, int n_tensors, long long total_chunks, const adcdiff_adamw_args* a,
-                                       float* grad_norm, void* workspace, size_t workspace_bytes, adcdiff_stream_t stream_) {
-    using namespace adcdiff;
-    if (!tensors || !a || n_tensors <= 0 || total_chunks <= 0 || total_chunks > 0x7fffffffLL)
-        return fail(ADCDIFF_E_BADARG, "clip_adamw_step: null table / args or %d tensors, %lld chunks", n_tensors, total_chunks);
-    if (!workspace || !aligned16(workspace) || workspace_bytes < adcdiff_clip_adamw_workspace_bytes(total_chunks))
-        return fail(ADCDIFF_E_WORKSPACE, "clip_adamw_step: workspace of %zu bytes, %zu needed", workspace_bytes,
-                    adcdiff_clip_adamw_workspace_bytes(total_chunks));
-    if (a->step < 1 || !(a->beta1 >= 0.0 && a->beta1 < 1.0) || !(a->beta2 >= 0.0 && a->beta2 < 1.0) || !(a->eps >= 0.0))
-        return fail(ADCDIFF_E_BADARG, "clip_adamw_step: step %d, betas (%g, %g), eps %g", a->step, a->beta1, a->beta2, a->eps);
-    hipStream_t st = as_stream(stream_);
-    float* scal = reinterpret_cast<float*>(workspace);          // [0] norm, [1] clip factor
-    float* partial = scal + 64;
+namespace adcdiff {
+
+// The three launches of the clipped step.  scal: 64 floats ([0] norm, [1] clip factor); partial: one float per chunk.  Every
+// word of both that a kernel reads was written earlier in the same call, so neither has to be cleared.
+static int clip_adamw_launch(const adcdiff_opt_tensor* tensors, int n_tensors, long long total_chunks, const adcdiff_adamw_args* a,
+                             float* grad_norm, float* scal, float* partial, hipStream_t st) {
+    TimingScope ts(ADCDIFF_KIND_OTHER, n_tensors, 0, 0, 0.0, (double)total_chunks * ADCDIFF_OPT_CHUNK * 32.0, st);
     hipLaunchKernelGGL(opt_sumsq_kernel, dim3((unsigned)total_chunks), dim3(256), 0, st, tensors, n_tensors, partial);
     hipLaunchKernelGGL(opt_norm_kernel, dim3(1), dim3(1024), 0, st, partial, total_chunks, (float)a->max_norm, scal, grad_norm);
     // scalars as torch forms them: python floats (double) rounded to float where they meet the float32 tensors
@@ -608,17 +609,38 @@ extern "C" int adcdiff_clip_adamw_step(const adcdiff_opt_tensor* tensors, int n_
     return check_launch("clip_adamw_step");
 }
 
+static int clip_adamw_check(const char* who, const adcdiff_opt_tensor* tensors, int n_tensors, long long total_chunks, const adcdiff_adamw_args* a) {
+    if (!tensors || !a || n_tensors <= 0 || total_chunks <= 0 || total_chunks > 0x7fffffffLL)
+        return fail(ADCDIFF_E_BADARG, "%s: null table / args or %d tensors, %lld chunks", who, n_tensors, total_chunks);
+    if (a->step < 1 || !(a->beta1 >= 0.0 && a->beta1 < 1.0) || !(a->beta2 >= 0.0 && a->beta2 < 1.0) || !(a->eps >= 0.0))
+        return fail(ADCDIFF_E_BADARG, "%s: step %d, betas (%g, %g), eps %g", who, a->step, a->beta1, a->beta2, a->eps);
+    return ADCDIFF_OK;
+}
+
+}  // namespace adcdiff
+
+extern "C" int adcdiff_clip_adamw_step(const adcdiff_opt_tensor* tensors, int n_tensors, long long total_chunks, const adcdiff_adamw_args* a,
+                                       float* grad_norm, void* workspace, size_t workspace_bytes, adcdiff_stream_t stream_) {
+    using namespace adcdiff;
+    TRY_RC(clip_adamw_check("clip_adamw_step", tensors, n_tensors, total_chunks, a));
+    if (!workspace || !aligned16(workspace) || workspace_bytes < adcdiff_clip_adamw_workspace_bytes(total_chunks))
+        return fail(ADCDIFF_E_WORKSPACE, "clip_adamw_step: workspace of %zu bytes, %zu needed", workspace_bytes,
+                    adcdiff_clip_adamw_workspace_bytes(total_chunks));
+    float* scal = reinterpret_cast<float*>(workspace);          // [0] norm, [1] clip factor
+    return clip_adamw_launch(tensors, n_tensors, total_chunks, a, grad_norm, scal, scal + 64, as_stream(stream_));
+}
+
 extern "C" int adcdiff_timing_begin(int max_records) {
     if (max_records <= 0) return fail(ADCDIFF_E_BADARG, "timing_begin: max_records=%d", max_records);
     if (g_timing.on) return fail(ADCDIFF_E_BADARG, "timing_begin: already active");
     if (g_timing.cap < max_records) {
-        for (int i = 0; i < 2 * g_timing.cap; ++i) (void)hipEventDestroy(g_timing.ev[i]);
+        for (int i = 0; i < (g_timing.cap ? g_timing.cap + 1 : 0); ++i) (void)hipEventDestroy(g_timing.ev[i]);
         delete[] g_timing.ev;
         delete[] g_timing.rec;
-        g_timing.ev = new hipEvent_t[2 * (size_t)max_records];
+        g_timing.ev = new hipEvent_t[(size_t)max_records + 1];
         g_timing.rec = new adcdiff_timing_record[max_records];
         g_timing.cap = 0;
-        for (int i = 0; i < 2 * max_records; ++i) {
+        for (int i = 0; i < max_records + 1; ++i) {
             hipError_t e = hipEventCreate(&g_timing.ev[i]);
             if (e != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "timing_begin: hipEventCreate: %s", hipGetErrorString(e));
         }
@@ -633,30 +655,16 @@ extern "C" int adcdiff_timing_end(adcdiff_timing_record* out, int capacity, int*
     if (!g_timing.on) return fail(ADCDIFF_E_BADARG, "timing_end: not active");
     g_timing.on = false;
     if (!out || !count) return fail(ADCDIFF_E_BADARG, "timing_end: null output");
-    int n = g_timing.used < capacity ? g_timing.used : capacity;
-    // what an event pair costs by itself: nine empty pairs on the stream the launches used, the median is subtracted
-    float empty = 0.0f;
-    if (n > 0) {
-        hipEvent_t ev[18];
-        float t[9];
-        bool ok = true;
-        for (int i = 0; i < 18; ++i) ok = ok && hipEventCreate(&ev[i]) == hipSuccess;
-        for (int i = 0; ok && i < 9; ++i) {
-            ok = hipEventRecord(ev[2 * i], g_timing.last_stream) == hipSuccess && hipEventRecord(ev[2 * i + 1], g_timing.last_stream) == hipSuccess;
-        }
-        for (int i = 0; ok && i < 9; ++i)
-            ok = hipEventSynchronize(ev[2 * i + 1]) == hipSuccess && hipEventElapsedTime(&t[i], ev[2 * i], ev[2 * i + 1]) == hipSuccess;
-        if (ok) {
-            std::sort(t, t + 9);
-            empty = t[4];
-        }
-        for (int i = 0; i < 18; ++i) (void)hipEventDestroy(ev[i]);
-    }
-    for (int i = 0; i < n; ++i) {
-        hipError_t e = hipEventSynchronize(g_timing.ev[2 * i + 1]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&g_timing.rec[i].ms, g_timing.ev[2 * i], g_timing.ev[2 * i + 1]);
+    const int used = g_timing.used;
+    if (used > 0) {
+        hipError_t e = hipEventRecord(g_timing.ev[used], g_timing.last_stream);   // closes the last launch's span
+        if (e == hipSuccess) e = hipEventSynchronize(g_timing.ev[used]);
         if (e != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "timing_end: %s", hipGetErrorString(e));
-        g_timing.rec[i].ms = g_timing.rec[i].ms > empty ? g_timing.rec[i].ms - empty : 0.0f;
+    }
+    const int n = used < capacity ? used : capacity;
+    for (int i = 0; i < n; ++i) {
+        hipError_t e = hipEventElapsedTime(&g_timing.rec[i].ms, g_timing.ev[i], g_timing.ev[i + 1]);
+        if (e != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "timing_end: %s", hipGetErrorString(e));
         out[i] = g_timing.rec[i];
     }
     *count = n;

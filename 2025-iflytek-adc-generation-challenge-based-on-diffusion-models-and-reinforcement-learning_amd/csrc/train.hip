@@ -229,6 +229,7 @@ template <typename InT>
 static int cast_transpose(const InT* src, long lds_, int rows, int rows_pad, int cols, int out_dtype, void* dst_rm, long ldrm, void* dst_t,
                           long ldt, float* colsum, hipStream_t st) {
     if (cols % 64 != 0) return fail(ADCDIFF_E_BADARG, "cast_transpose: cols=%d must be a multiple of 64", cols);
+    TimingScope ts(ADCDIFF_KIND_OTHER, rows, cols, 0, 0.0, (double)rows * cols * (sizeof(InT) + (out_dtype == ADCDIFF_BF16 ? 2.0 : 4.0) * ((dst_rm ? 1 : 0) + (dst_t ? 1 : 0))), st);
     const dim3 grid((unsigned)((rows_pad + 63) / 64), (unsigned)(cols / 64));
     if (out_dtype == ADCDIFF_BF16)
         hipLaunchKernelGGL((cast_transpose_kernel<InT, bf16_t>), grid, dim3(256), 0, st, src, lds_, rows, rows_pad, cols,
@@ -264,6 +265,7 @@ static int gn_silu_bwd(const float* u, long ldu, const float* dA, long ldda, int
     float* part = (float*)ws.take((size_t)nby * 2 * C * 4);   // one (d gamma | d beta) row per workgroup row; dead after the column sums
     ws.off = keep;
     if (dry) return ADCDIFF_OK;
+    TimingScope ts(ADCDIFF_KIND_OTHER, rows, C, 0, 0.0, (double)rows * C * 12.0, st);
     const dim3 grid((unsigned)(c4 / c4t), (unsigned)nby);
     hipLaunchKernelGGL(gn_silu_bwd_kernel, grid, dim3(256), 0, st, u, ldu, dA, ldda, rows, c4t, rpt, gs / 4, 1.0f / (float)gs, gamma, beta, 1e-5f,
                        drop_p, drop_seed, drop_layer, drop_col0, add, ldadd, dst, lddst, accumulate, part, (long)2 * C);
@@ -316,11 +318,13 @@ static int gemm_dw(int dt, const void* A, const void* W, int M, int N, int K, fl
     g.split_k = slices; g.split_stride = (long long)M * N;
     TRY(gemm_dispatch(g, st));
     const long n4 = (long)M * N / 4;
+    TimingScope ts(ADCDIFF_KIND_OTHER, M, N, 0, 0.0, (double)M * N * 4.0 * (slices + 1), st);
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, slices, (long)M * N, n4, out);
     return check_launch("sum_partials");
 }
 
 static int copy_f32(const float* src, float* dst, long n, int accumulate, hipStream_t st) {
+    TimingScope ts(ADCDIFF_KIND_OTHER, 1, 0, 0, 0.0, (double)n * 8.0, st);
     hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, accumulate);
     return check_launch("copy_f32");
 }
@@ -373,6 +377,7 @@ extern "C" int adcdiff_mse_loss_grad(const float* pred, int ldp, const float* ta
     if (!pred || !target || !dpred || !loss_accum || B <= 0 || D <= 0 || ldp < D || ldt < D || ldd < D)
         return fail(ADCDIFF_E_BADARG, "mse_loss_grad: bad arguments");
     const long nel = (long)B * D;
+    TimingScope ts(ADCDIFF_KIND_OTHER, B, D, 0, 0.0, (double)B * D * 12.0, as_stream(stream_));
     hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)((nel + 4095) / 4096)), dim3(256), 0, as_stream(stream_), pred, (long)ldp, target, (long)ldt,
                        dpred, (long)ldd, B, D, scale, loss_accum);
     return check_launch("mse_loss_grad");
@@ -481,6 +486,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         {
             const long total = (long)B * cout;
             if (!dry) {
+                TimingScope ts(ADCDIFF_KIND_OTHER, B, cout, 0, 0.0, (double)total * 12.0, st);
                 hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_h1, (long)cout, tp.t_rows, B,
                                    cout, d_tb, (long)SN, b.tb_off, n->T);
                 TRY(check_launch("scatter_add_rows"));
@@ -525,6 +531,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         RUN(gemm_simple(ADCDIFF_F32, d_tb, SN, wtpT, SN, Tp, 0, H, SN, d_s, H, st));
         float* d_te = (float*)ws.take((size_t)Tp * H * 4);
         if (!dry) {
+            TimingScope ts(ADCDIFF_KIND_OTHER, Tp, H, 0, 0.0, (double)Tp * H * 12.0, st);
             hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)(((long)Tp * H + 255) / 256)), dim3(256), 0, st, n->te_table, d_s, d_te, (long)Tp * H);
             TRY(check_launch("silu_bwd"));
         }
@@ -539,6 +546,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         RUN(gemm_simple(ADCDIFF_F32, d_te, H, w2T, H, Tp, 0, 4 * H, H, d_hid, 4 * H, st));
         float* d_pre = (float*)ws.take((size_t)Tp * 4 * H * 4);
         if (!dry) {
+            TimingScope ts(ADCDIFF_KIND_OTHER, Tp, 4 * H, 0, 0.0, (double)Tp * 4 * H * 12.0, st);
             hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)(((long)Tp * 4 * H + 255) / 256)), dim3(256), 0, st, n->te_pre, d_hid, d_pre, (long)Tp * 4 * H);
             TRY(check_launch("silu_bwd"));
         }

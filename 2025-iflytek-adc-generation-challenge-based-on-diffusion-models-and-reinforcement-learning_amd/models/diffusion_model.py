@@ -41,7 +41,7 @@ import torch.nn.functional as F
 from torch.optim import Adam, AdamW
 from torch.optim.lr_scheduler import CosineAnnealingLR, OneCycleLR
 
-from .. import _lib, ops
+from .. import _lib, ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.adcdiff.*)
 from .._lib import AdcdiffError, check
 
 
@@ -277,14 +277,9 @@ def _taped_forward_loss(model, x_noisy, t, noise, dropout_p, dropout_seed):
     eng = model.engine()
     handle = eng.ensure(dev)
     B = x_noisy.shape[0]
-    ws, ws_bytes = eng.train_workspace_for(B, dev)
-    eps = torch.empty((B, model.output_dim), device=dev, dtype=torch.float32)
-    check(eng.lib.adcdiff_unet_train_forward(handle, ops._ptr(x_noisy), x_noisy.stride(0), B, ops._ptr(t), float(dropout_p),
-                                             int(dropout_seed), ops._ptr(eps), model.output_dim, ws, ws_bytes, ops._stream()))
-    loss = torch.zeros((), device=dev, dtype=torch.float32)
-    d_eps = torch.empty_like(eps)
-    check(eng.lib.adcdiff_mse_loss_grad(ops._ptr(eps), model.output_dim, ops._ptr(noise), noise.stride(0), ops._ptr(d_eps),
-                                        model.output_dim, B, model.output_dim, 1.0, ops._ptr(loss), ops._stream()))
+    eng.train_workspace_for(B, dev)
+    eps = torch.ops.adcdiff.unet_train_forward(handle.value, x_noisy, t, float(dropout_p), int(dropout_seed), model.output_dim, eng.workspace)
+    loss, d_eps = torch.ops.adcdiff.mse_loss_grad(eps, noise, 1.0)
     return loss, d_eps, eng, handle, eng.workspace, eng.generation
 
 
@@ -332,9 +327,8 @@ class _NoisePredictionLoss(torch.autograd.Function):
             by_param[id(p)] = g
             target = grads if len(path) == 1 else grads.blocks[path[0]]
             setattr(target, path[-1], g.data_ptr())
-        ws = C.c_void_p(ctx.ws_tensor.data_ptr())
-        check(eng.lib.adcdiff_unet_backward(ctx.handle, ops._ptr(ctx.d_eps), model.output_dim, C.byref(grads), ws, ctx.ws_tensor.numel(),
-                                            ops._stream()))
+        table = torch.frombuffer(bytearray(bytes(grads)), dtype=torch.int64)     # the adcdiff_unet_grads struct as a CPU tensor
+        torch.ops.adcdiff.unet_backward(ctx.handle.value, ctx.d_eps, table, flat, ctx.ws_tensor)
         eng.generation += 1                  # the tape is consumed
         flat.mul_(grad_out)                  # d(loss * c) = c * d(loss): one pass over the arena, no host sync
         out = []
@@ -458,10 +452,8 @@ class UNetModel(nn.Module):
             condition = self.expand_condition(condition, batch)
         cond = condition.to(device=dev, dtype=torch.float32).contiguous()
         B = cond.shape[0]
-        ws, ws_bytes = eng.workspace_for(B, dev)
-        cemb = torch.empty((B, self.hidden_dim), device=dev, dtype=torch.float32)
-        check(eng.lib.adcdiff_unet_condition_embed(handle, ops._ptr(cond), cond.stride(0), B, ops._ptr(cemb), self.hidden_dim, ws,
-                                                   ws_bytes, ops._stream()))
+        eng.workspace_for(B, dev)
+        cemb = torch.ops.adcdiff.condition_embed(handle.value, cond, self.hidden_dim, eng.workspace)
         if batch is not None and B == 1 and batch > 1:
             cemb = cemb.expand(batch, -1).contiguous()
         return cemb
@@ -478,11 +470,8 @@ class UNetModel(nn.Module):
         if x.shape[1] != self.input_dim or t.shape[0] != B:
             raise ValueError("x must be [B, %d] and t [B]" % self.input_dim)
         cemb = self.condition_embedding(condition, batch=B) if condition is not None else None
-        ws, ws_bytes = eng.workspace_for(B, dev)
-        eps = torch.empty((B, self.output_dim), device=dev, dtype=torch.float32)
-        check(eng.lib.adcdiff_unet_forward(handle, ops._ptr(x), x.stride(0), B, ops._ptr(t), 0, ops._ptr(cemb), self.hidden_dim,
-                                           ops._ptr(eps), self.output_dim, ws, ws_bytes, ops._stream()))
-        return eps
+        eng.workspace_for(B, dev)
+        return torch.ops.adcdiff.unet_forward(handle.value, x, t, cemb, self.output_dim, eng.workspace)
 
 
 class DiffusionModel(nn.Module):
@@ -603,6 +592,13 @@ class DiffusionModel(nn.Module):
             self._tables["ddpm_c"] = arr
         return self._tables["ddpm_c"]
 
+    def _ddpm_coef_tensor(self):
+        """The per-timestep adcdiff_ddpm_coef structs as a CPU float32 [T, 4] tensor (what torch.ops.adcdiff.ddpm_sample_loop takes)."""
+        if "ddpm_t" not in self._tables:
+            tb = self._host_tables()
+            self._tables["ddpm_t"] = torch.stack([tb["sra"], tb["beta"], tb["s1m"], tb["sigma"]], dim=1).to(torch.float32).contiguous()
+        return self._tables["ddpm_t"]
+
     def _device_tables(self):
         if "dev" not in self._tables:
             self._tables["dev"] = dict(sqrt_ac=torch.sqrt(self._host["alpha_cumprod"]).to(self.device),
@@ -678,17 +674,15 @@ class DiffusionModel(nn.Module):
         dev, eng, handle, cemb, ws, ws_bytes = self._sampling_setup(b, condition)
         if seed is None:
             seed = _seed_from_torch()
-        img = x_T.to(device=dev, dtype=torch.float32).clone().contiguous() if x_T is not None else \
+        img = x_T.to(device=dev, dtype=torch.float32).contiguous() if x_T is not None else \
             ops.philox_normal(b, d, seed, _lib.STREAM_XT, 0, row_offset, dev)
         first = self.num_timesteps - 1 if t_start is None else int(t_start)
         stride = 0
         if noise is not None:
             noise = noise.to(device=dev, dtype=torch.float32).contiguous()
             stride = noise.stride(0)
-        check(eng.lib.adcdiff_ddpm_sample_loop(handle, ops._ptr(img), img.stride(0), b, ops._ptr(cemb), self.hidden_dim,
-                                               self._ddpm_coef_array(), first, int(t_stop), ops._ptr(noise), stride, seed,
-                                               row_offset, ws, ws_bytes, ops._stream()))
-        return img
+        return torch.ops.adcdiff.ddpm_sample_loop(handle.value, img, cemb, self._ddpm_coef_tensor(), first, int(t_stop), noise, int(seed),
+                                                  int(row_offset), eng.workspace)
 
     def _p_sample_loop_chunk(self, img: torch.Tensor, condition: Optional[torch.Tensor] = None) -> torch.Tensor:
         """diffusion_model.py:263-281 (the reference's version reads a missing attribute)."""
@@ -738,16 +732,16 @@ class DiffusionModel(nn.Module):
         dev, eng, handle, cemb, ws, ws_bytes = self._sampling_setup(b, condition)
         if seed is None:
             seed = _seed_from_torch()
-        img = x_T.to(device=dev, dtype=torch.float32).clone().contiguous() if x_T is not None else \
+        img = x_T.to(device=dev, dtype=torch.float32).contiguous() if x_T is not None else \
             ops.philox_normal(b, d, seed, _lib.STREAM_XT, 0, row_offset, dev)
         steps, coef = self._ddim_plan(ddim_steps, eta)
         stride = 0
         if noise is not None:
             noise = noise.to(device=dev, dtype=torch.float32).contiguous()
             stride = noise.stride(0)
-        check(eng.lib.adcdiff_ddim_sample_loop(handle, ops._ptr(img), img.stride(0), b, ops._ptr(cemb), self.hidden_dim, steps, coef,
-                                               ddim_steps, ops._ptr(noise), stride, seed, row_offset, ws, ws_bytes, ops._stream()))
-        return img
+        steps_t = torch.tensor(list(steps), dtype=torch.int32)
+        coef_t = torch.tensor([[c.c_eps, c.sqrt_ac_t, c.sqrt_ac_prev, c.dir_coef, c.sigma] for c in coef], dtype=torch.float32)
+        return torch.ops.adcdiff.ddim_sample_loop(handle.value, img, cemb, steps_t, coef_t, noise, int(seed), int(row_offset), eng.workspace)
 
     def _ddim_sample_chunked(self, shape: Tuple, condition: Optional[torch.Tensor] = None, ddim_steps: int = 50,
                              eta: float = 0.0) -> torch.Tensor:

@@ -3,6 +3,10 @@
 torch is used here for device memory and the current stream only; every arithmetic step is a call
 into libadcdiff.so.  All functions require CUDA (ROCm) tensors and raise otherwise: there is no CPU
 path.
+
+The public functions (gemm, groupnorm_silu, philox_normal, ddpm_step, ddim_step, q_sample, latent_summary) go through
+the PyTorch dispatcher: they call the custom operators ``torch.ops.adcdiff.*`` registered in ``torch_ops.py``
+(torch.library.custom_op with fake-tensor rules), whose implementations are the ``_raw_*`` ctypes wrappers below.
 """
 import ctypes as C
 
@@ -46,7 +50,7 @@ def _operand(x, code):
     return buf
 
 
-def gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, act=0, out_f32=True, out_op=False, gn=(),
+def _raw_gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, act=0, out_f32=True, out_op=False, gn=(),
          m_valid=None, dtype="fp32", eps=1e-5, tile_hint=0, split_k=0):
     """adcdiff_gemm: v = [A0|A1|A2] @ w.T + bias + rowbias + residual.
 
@@ -110,7 +114,7 @@ def linear(x, weight, bias, act=0, dtype="fp32"):
     return out[:B]
 
 
-def groupnorm_silu(x, groups, gamma, beta, eps=1e-5, out_dtype="fp32", with_raw=False):
+def _raw_groupnorm_silu(x, groups, gamma, beta, eps=1e-5, out_dtype="fp32", with_raw=False):
     lib = _lib.load()
     _need_gpu(x, gamma, beta)
     code = dtype_code(out_dtype)
@@ -123,7 +127,7 @@ def groupnorm_silu(x, groups, gamma, beta, eps=1e-5, out_dtype="fp32", with_raw=
     return (out, raw) if with_raw else out
 
 
-def philox_normal(rows, cols, seed, stream_id, step, row_offset=0, device="cuda"):
+def _raw_philox_normal(rows, cols, seed, stream_id, step, row_offset=0, device="cuda"):
     lib = _lib.load()
     out = torch.empty((rows, cols), device=device, dtype=torch.float32)
     _need_gpu(out)
@@ -131,7 +135,7 @@ def philox_normal(rows, cols, seed, stream_id, step, row_offset=0, device="cuda"
     return out
 
 
-def ddpm_step(x, eps, coef, noise=None, seed=0, step=0, row_offset=0, out=None):
+def _raw_ddpm_step(x, eps, coef, noise=None, seed=0, step=0, row_offset=0, out=None):
     lib = _lib.load()
     _need_gpu(x, eps, noise)
     B, D = x.shape
@@ -143,7 +147,7 @@ def ddpm_step(x, eps, coef, noise=None, seed=0, step=0, row_offset=0, out=None):
     return out
 
 
-def ddim_step(x, eps, coef, noise=None, seed=0, step=0, row_offset=0, out=None):
+def _raw_ddim_step(x, eps, coef, noise=None, seed=0, step=0, row_offset=0, out=None):
     lib = _lib.load()
     _need_gpu(x, eps, noise)
     B, D = x.shape
@@ -155,7 +159,7 @@ def ddim_step(x, eps, coef, noise=None, seed=0, step=0, row_offset=0, out=None):
     return out
 
 
-def q_sample(x0, t, sqrt_ac, sqrt_1mac, noise=None, seed=0, step=0, row_offset=0, return_noise=False):
+def _raw_q_sample(x0, t, sqrt_ac, sqrt_1mac, noise=None, seed=0, step=0, row_offset=0, return_noise=False):
     lib = _lib.load()
     _need_gpu(x0, t, sqrt_ac, sqrt_1mac, noise)
     B, D = x0.shape
@@ -167,7 +171,7 @@ def q_sample(x0, t, sqrt_ac, sqrt_1mac, noise=None, seed=0, step=0, row_offset=0
     return (out, nz_out) if return_noise else out
 
 
-def latent_summary(x):
+def _raw_latent_summary(x):
     """[B, D] float32 latents -> [B, 5] float32 (mean, sum, x[:, 3], x[:, 5], x[:, 8]) with numpy's float32 summation order."""
     lib = _lib.load()
     _need_gpu(x)
@@ -197,3 +201,59 @@ class timing:
         check(_lib.load().adcdiff_timing_end(buf, self.max_records, C.byref(n)))
         self.records = [dict(kind=r.kind, M=r.M, N=r.N, K=r.K, ms=r.ms, flops=r.flops, bytes=r.bytes) for r in buf[:n.value]]
         return False
+
+
+# ---- public entry points: through torch.ops.adcdiff.* (registered in torch_ops.py) ----------------------------------
+def gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, act=0, out_f32=True, out_op=False, gn=(),
+         m_valid=None, dtype="fp32", eps=1e-5, tile_hint=0, split_k=0):
+    """adcdiff_gemm through the dispatcher; arguments and results as _raw_gemm."""
+    from . import torch_ops  # noqa: F401  (registers the operators)
+    outs = torch.ops.adcdiff.gemm(list(a_list), w, bias, rowbias, rowbias_idx, residual, int(act), bool(out_f32), bool(out_op),
+                                  [g[0] for g in gn], [g[1] for g in gn], [int(g[2]) for g in gn], 0 if m_valid is None else int(m_valid),
+                                  dtype_code(dtype), float(eps), int(tile_hint), int(split_k))
+    return outs[0] if len(outs) == 1 else tuple(outs)
+
+
+def groupnorm_silu(x, groups, gamma, beta, eps=1e-5, out_dtype="fp32", with_raw=False):
+    from . import torch_ops  # noqa: F401
+    outs = torch.ops.adcdiff.groupnorm_silu(x, int(groups), gamma, beta, float(eps), dtype_code(out_dtype), bool(with_raw))
+    return (outs[0], outs[1]) if with_raw else outs[0]
+
+
+def philox_normal(rows, cols, seed, stream_id, step, row_offset=0, device="cuda"):
+    from . import torch_ops  # noqa: F401
+    return torch.ops.adcdiff.philox_normal(int(rows), int(cols), int(seed), int(stream_id), int(step), int(row_offset), torch.device(device))
+
+
+def ddpm_step(x, eps, coef, noise=None, seed=0, step=0, row_offset=0, out=None):
+    from . import torch_ops  # noqa: F401
+    c = [float(v) for v in coef]
+    res = torch.ops.adcdiff.ddpm_step(x, eps, noise, c[0], c[1], c[2], c[3], int(seed), int(step), int(row_offset))
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def ddim_step(x, eps, coef, noise=None, seed=0, step=0, row_offset=0, out=None):
+    from . import torch_ops  # noqa: F401
+    c = [float(v) for v in coef]
+    res = torch.ops.adcdiff.ddim_step(x, eps, noise, c[0], c[1], c[2], c[3], c[4], int(seed), int(step), int(row_offset))
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def q_sample(x0, t, sqrt_ac, sqrt_1mac, noise=None, seed=0, step=0, row_offset=0, return_noise=False):
+    from . import torch_ops  # noqa: F401
+    out, used = torch.ops.adcdiff.q_sample(x0, t, sqrt_ac, sqrt_1mac, noise, int(seed), int(step), int(row_offset))
+    return (out, used) if return_noise else out
+
+
+def latent_summary(x):
+    """[B, D] float32 latents -> [B, 5] float32 (mean, sum, x[:, 3], x[:, 5], x[:, 8]) with numpy's float32 summation order."""
+    from . import torch_ops  # noqa: F401
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("latent_summary expects a [B, D] float32 tensor with contiguous rows")
+    return torch.ops.adcdiff.latent_summary(x)

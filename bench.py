@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
-"""Benchmark of the DDPM sampling hot path on MI355X.
+"""Benchmark of the DDPM hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload bf16_b65536|fp32_b4096]
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--condition] [--sampler ddpm|ddim50]
 
-One "step" is one full pass of the hot path over one batch: the T = 1000 reverse loop
-(p_sample_loop: denoiser forward + fused schedule update per timestep) on `batch` synthetic samples per
-GPU, emb 512 / hidden 256, random weights of that architecture, inputs generated on the device.  With
-N > 1 (launched by torch.distributed.run, one rank per GPU) every rank samples its own shard of rows
-(counter-RNG row offset = rank * batch, so the job equals one N*batch-row run) and the latents are
-collected by one RCCL all-gather inside the timed region.  Rank 0 prints ONE JSON line.
+Workloads (emb 512 / hidden 256, random weights of that architecture, inputs generated on the device):
+
+* ``bf16_b65536`` (default; BASELINE configs[2]) and ``fp32_b4096`` (configs[1]): one "step" is one full pass of the hot
+  path over one batch -- the T = 1000 reverse loop (p_sample_loop: denoiser forward + fused schedule update per timestep)
+  on `batch` samples per GPU.  With N > 1 every rank samples its own rows (counter-RNG row offset = rank * batch, so the
+  job equals one N * batch-row run) and the latents are collected by one RCCL all-gather inside the timed region
+  (weak scaling).  ``--condition`` adds the generator's one-row condition repeated to the batch
+  (molecule_generator.py:238-245); ``--sampler ddim50`` times the generator's default sampler instead (50 DDIM steps).
+* ``shard_1m`` (configs[3]): 1 048 576 samples in total, sharded by rows over the N ranks (parallel.shard_rows), bf16,
+  all-gather of the [1048576, 512] latents in the timed region; strong scaling.
+* ``train_dp`` (configs[4]): one "step" is one train_step (q_sample, denoiser forward + backward in the HIP library,
+  gradient all-reduce over the ranks, fused clip + AdamW) at batch 4096 per GPU, bf16 operands / fp32 master weights.
+
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -23,27 +32,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import adcdiff  # noqa: E402
-from adcdiff import _lib, ops  # noqa: E402
+from adcdiff import _lib, ops, parallel  # noqa: E402
 
 WORKLOADS = {
     # name: (compute dtype, per-GPU batch, description of the configuration)
     "bf16_b65536": ("bf16", 65536, "configs[2]: bf16 MFMA denoiser GEMMs, batch 65536 on 1 MI355X"),
     "fp32_b4096": ("fp32", 4096, "configs[1]: same denoiser, fp32 on 1 MI355X, batch 4096"),
+    "shard_1m": ("bf16", 1048576, "configs[3]: 1M samples sharded over the GPUs, RCCL all-gather of latents"),
+    "train_dp": ("bf16", 4096, "configs[4]: denoiser train step (q_sample noise-pred loss fwd+bwd), data parallel, batch 4096 per GPU"),
 }
 DIMS = (512, 256, 512)
 ALGO_FLOP_PER_SAMPLE_STEP = 81.92e6     # 2 * 40 960 000 MACs: denoiser linears with the time term hoisted
+ALGO_FLOP_PER_SAMPLE_STEP_COND = 87.03e6   # + 2 * 2 555 904: the ten time_proj layers are per row with a condition
+TRAIN_FLOP_PER_SAMPLE = 3 * 88.08e6     # forward as executed (per-row timesteps: nothing hoisted) + two backward GEMMs per layer
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 PEAK_HBM_GBS = 8000.0
 SEED = 2025
 
 
-def build_model(dtype, device):
+def build_model(dtype, device, **extra):
     """The denoiser at emb 512 / hidden 256 with synthetic weights drawn on the device from the library's counter RNG
     (stream 100 + parameter index, so every rank builds the same tensors without a checkpoint): Linear weights
     N(0, 2 / (fan_in + fan_out)) -- the variance of the reference's xavier_uniform_ init --, biases N(0, 0.05^2), GroupNorm
     weight 1 + N(0, 0.1^2)."""
     cfg = dict(input_dim=DIMS[0], hidden_dim=DIMS[1], output_dim=DIMS[2], num_timesteps=1000, beta_start=1e-4, beta_end=2e-2,
-               compute_dtype=dtype, memory_monitor_enabled=False)
+               compute_dtype=dtype, memory_monitor_enabled=False, **extra)
     model = adcdiff.DiffusionModel(cfg)
     with torch.no_grad():
         for i, (name, p) in enumerate(model.model.named_parameters()):
@@ -58,7 +71,7 @@ def build_model(dtype, device):
     return model
 
 
-def measured_traffic(kernel_key, dtype, batch):
+def measured_traffic(kernel_key, workload):
     """HBM bytes per launch of a kernel from the newest committed counter summary of this same workload (profiles/*_traffic.json,
     produced by profiles/collect.sh + summarize.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this benchmark)."""
     import glob
@@ -67,7 +80,10 @@ def measured_traffic(kernel_key, dtype, batch):
         try:
             d = json.load(open(f))
             line = d.get("bench_line_under_profiler", {})
-            if line.get("dtype") != dtype or line.get("config", {}).get("per_gpu_batch") != batch:
+            cfg = line.get("config", {})
+            name = cfg.get("workload_name") or ("bf16_b65536" if line.get("dtype") == "bf16" and cfg.get("per_gpu_batch") == 65536 else
+                                                "fp32_b4096" if line.get("dtype") == "fp32" and cfg.get("per_gpu_batch") == 4096 else None)
+            if name != workload or cfg.get("condition") or cfg.get("sampler_name", "ddpm") != "ddpm":
                 continue
             v = d["kernels"].get(kernel_key, {}).get("hbm_bytes_per_launch")
             if v:
@@ -77,62 +93,84 @@ def measured_traffic(kernel_key, dtype, batch):
     return best
 
 
-def roofline(model, dtype, batch, window=8):
-    """Live per-launch hipEvent timing (on the stream the kernels run on) of `window` denoising steps.
-
-    `dominant`: the kernel with the largest share of the step -- the 256 x 256-tile bf16 GEMM (bf16 workload) or the
-    float32 GEMM -- achieved = FLOPs of its launches (2 M N K each, the layer as executed) / their device time.
-    `gemms`: every GEMM launch of the step against the algorithmic 81.92 MFLOP per sample and step.
-    Schedule-update and GroupNorm kernels: algorithmic bytes / device time."""
-    with ops.timing(64 * window + 64) as tm:
-        model.p_sample_loop((batch, DIMS[2]), seed=SEED, t_start=999, t_stop=1000 - window)
+def timed_window(fn):
+    """Run fn() twice on the current stream: once between ONE pair of events (the window's true device time) and once with
+    an event in front of every launch (ops.timing).  Recording an event costs the stream a few microseconds, so the second
+    run's spans add up to more than the first run's time; the excess is taken off every span in equal parts (it is a
+    per-event cost), which makes the records add up to the un-instrumented window exactly."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    clean_ms = e0.elapsed_time(e1)
+    with ops.timing(4096) as tm:
+        fn()
         torch.cuda.synchronize()
-    gemm_kinds = (_lib.KIND_GEMM_BF16, _lib.KIND_GEMM_BF16_T256) if dtype == "bf16" else (_lib.KIND_GEMM_F32,)
-    gemm = [r for r in tm.records if r["kind"] in gemm_kinds]
-    big = [r for r in gemm if r["kind"] == _lib.KIND_GEMM_BF16_T256]
-    dom, dom_name, dom_key = (big, "gemm256_bf16_kernel", "gemm256_kernel<bf16>") if big else \
-        (gemm, "gemm_nt_kernel<%s>" % ("bf16" if dtype == "bf16" else "float"), "gemm_nt_kernel<%s>" % ("bf16" if dtype == "bf16" else "float"))
-    upd = [r for r in tm.records if r["kind"] == _lib.KIND_UPDATE]
-    gn = [r for r in tm.records if r["kind"] == _lib.KIND_GROUPNORM]
-    peak = PEAK_TFLOPS[dtype]
+    recs = tm.records
+    over = (sum(r["ms"] for r in recs) - clean_ms) / max(1, len(recs))
+    for r in recs:
+        r["ms"] = max(r["ms"] - over, 1e-6)
+    return recs, clean_ms, over
 
+
+def summarize_records(records, dtype, units, algo_flop_per_unit, workload):
+    """Roofline objects from per-launch records (timed_window): `units` = samples x denoising steps (or training samples)
+    inside the window.  The record times add up to the window's device time."""
+    gemm_kinds = (_lib.KIND_GEMM_BF16, _lib.KIND_GEMM_BF16_T256, _lib.KIND_GEMM_F32)
+    gemm = [r for r in records if r["kind"] in gemm_kinds]
+    big = [r for r in gemm if r["kind"] == _lib.KIND_GEMM_BF16_T256]
+    small_name = "gemm_nt_kernel<%s>" % ("bf16" if dtype == "bf16" else "float")
+    dom, dom_name, dom_key = (big, "gemm256_bf16_kernel", "gemm256_kernel<bf16>") if big else (gemm, small_name, small_name)
+    peak = PEAK_TFLOPS[dtype]
+    window_ms = sum(r["ms"] for r in records)
     dom_ms = sum(r["ms"] for r in dom)
     dom_fl = sum(r["flops"] for r in dom)
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12
     main = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": None, "launches": len(dom), "avg_launch_ms": round(dom_ms / max(1, len(dom)), 4),
             "flop_per_launch": dom_fl / max(1, len(dom)), "algorithmic_bytes_per_launch": sum(r["bytes"] for r in dom) / max(1, len(dom)),
-            "share_of_gemm_time": round(dom_ms / max(1e-9, sum(r["ms"] for r in gemm)), 3)}
-    tr = measured_traffic(dom_key, dtype, batch)
+            "share_of_window": round(dom_ms / max(1e-9, window_ms), 3),
+            "timing": "hipEvent in front of every launch on the launch stream, span to the next launch's event, minus the per-event cost "
+                      "measured against the same window between one event pair"}
+    tr = measured_traffic(dom_key, workload)
     if tr:
         main["traffic"], main["traffic_source"] = tr[0], "profiles/" + tr[1]
     gemm_ms = sum(r["ms"] for r in gemm)
-    algo = ALGO_FLOP_PER_SAMPLE_STEP * batch * window
-    allg = {"bound": "mfma", "kernel": "all denoiser GEMM launches of a step", "achieved": round(algo / (gemm_ms * 1e-3) / 1e12, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(algo / (gemm_ms * 1e-3) / 1e12 / peak, 4), "launches_per_step": len(gemm) // window,
-            "algorithmic_flop_per_sample_step": ALGO_FLOP_PER_SAMPLE_STEP, "executed_flop_per_sample_step": sum(r["flops"] for r in gemm) / window / batch,
-            "gemm_ms_per_denoise_step": round(gemm_ms / window, 4)}
-    upd_ms = sum(r["ms"] for r in upd)
-    upd_bytes = sum(r["bytes"] for r in upd)
-    update = {"bound": "hbm", "kernel": "ddpm_step_kernel<false>", "achieved": round(upd_bytes / (upd_ms * 1e-3) / 1e9, 1),
-              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(upd_bytes / (upd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-              "traffic": None, "launches": len(upd), "avg_launch_ms": round(upd_ms / max(1, len(upd)), 4),
-              "bytes_per_launch": upd_bytes / max(1, len(upd))}
-    tr = measured_traffic("ddpm_step_kernel", dtype, batch)
-    if tr:
-        update["traffic"], update["traffic_source"] = tr[0], "profiles/" + tr[1]
-    gn_ms = sum(r["ms"] for r in gn)
-    gn_bytes = sum(r["bytes"] for r in gn)
-    norm = {"bound": "hbm", "kernel": "gn_silu_vec_kernel", "achieved": round(gn_bytes / (gn_ms * 1e-3) / 1e9, 1),
-            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gn_bytes / (gn_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-            "launches": len(gn), "ms_per_denoise_step": round(gn_ms / window, 4)}
-    return main, allg, update, norm
+    algo = algo_flop_per_unit * units
+    allg = {"bound": "mfma", "kernel": "all GEMM launches of the window", "achieved": round(algo / (gemm_ms * 1e-3) / 1e12, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(algo / (gemm_ms * 1e-3) / 1e12 / peak, 4), "launches": len(gemm),
+            "algorithmic_flop_per_unit": algo_flop_per_unit, "executed_flop_per_unit": sum(r["flops"] for r in gemm) / units,
+            "gemm_ms": round(gemm_ms, 4), "window_ms": round(window_ms, 4), "gemm_share_of_window": round(gemm_ms / max(1e-9, window_ms), 3)}
+    out = {"roofline": main, "roofline_all_gemms": allg}
+    for kind, key, kname in ((_lib.KIND_UPDATE, "roofline_schedule_update", "ddpm_step_kernel / ddim_step_kernel"),
+                             (_lib.KIND_GROUPNORM, "groupnorm_kernel", "gn_silu_vec_kernel"), (_lib.KIND_OTHER, "other_kernels", "casts, transposes, element-wise backward, optimizer")):
+        rs = [r for r in records if r["kind"] == kind]
+        if not rs:
+            continue
+        ms, by = sum(r["ms"] for r in rs), sum(r["bytes"] for r in rs)
+        out[key] = {"bound": "hbm", "kernel": kname, "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launches": len(rs), "avg_launch_ms": round(ms / len(rs), 4),
+                    "share_of_window": round(ms / max(1e-9, window_ms), 3)}
+    return out
 
 
-def cpu_baseline(weights, target_seconds=15.0):
-    """The CPU restatement (oracle.ddpm, numpy float32 + OpenBLAS) timed on this host on a bounded
-    sample of configs[0]: batch 32 (the reference's generation_batch_size), the first n of the 1000
-    reverse steps, scaled to samples/s at T = 1000."""
+def cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(weights, target_seconds=12.0):
+    """The CPU restatement (oracle.ddpm, numpy float32 + OpenBLAS) timed on this host on a bounded sample of configs[0]:
+    batch 32 (the reference's generation_batch_size), the first n of the 1000 reverse steps, scaled to samples/s at
+    T = 1000; plus a batch-4096 run of a few steps as the best case a CPU gets from batching."""
     from oracle import ddpm
     try:
         from threadpoolctl import threadpool_info
@@ -141,22 +179,29 @@ def cpu_baseline(weights, target_seconds=15.0):
         cores = os.cpu_count() or 1
     w = dict(weights)
     sched = ddpm.make_schedule(1000)
-    B, D = 32, DIMS[0]
-    x = ddpm.philox_x_T(SEED, 0, B, D)
-    nf = ddpm.philox_noise_fn(SEED, 0, B, D)
+    D = DIMS[0]
 
-    def run(n):
-        t0 = time.perf_counter()
-        ddpm.p_sample_loop(w, sched, x, None, nf, t_start=999, t_stop=1000 - n)
-        return time.perf_counter() - t0
+    def rate(B, budget, min_steps):
+        x = ddpm.philox_x_T(SEED, 0, B, D)
+        nf = ddpm.philox_noise_fn(SEED, 0, B, D)
 
-    run(3)
-    probe = run(10) / 10
-    n = int(max(20, min(1000, target_seconds / probe)))
-    per_step = run(n) / n
-    return {"value": round(B / (per_step * 1000), 4), "unit": "samples/s", "cores": int(cores), "kind": "port",
+        def run(n):
+            t0 = time.perf_counter()
+            ddpm.p_sample_loop(w, sched, x, None, nf, t_start=999, t_stop=1000 - n)
+            return time.perf_counter() - t0
+        run(2)
+        probe = run(4) / 4
+        n = int(max(min_steps, min(1000, budget / probe)))
+        per_step = run(n) / n
+        return B / (per_step * 1000), n, per_step
+
+    v32, n32, ps32 = rate(32, target_seconds, 20)
+    v4k, n4k, ps4k = rate(4096, target_seconds * 0.6, 3)
+    return {"value": round(v32, 4), "unit": "samples/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model_name(),
             "sample": "oracle.ddpm.p_sample_loop (numpy float32), emb 512/hidden 256, batch 32, %d of 1000 reverse steps "
-                      "timed (%.1f ms/step) and scaled to T=1000" % (n, per_step * 1e3)}
+                      "timed (%.1f ms/step) and scaled to T=1000" % (n32, ps32 * 1e3),
+            "best_case_batch_4096": {"value": round(v4k, 3), "unit": "samples/s",
+                                     "sample": "same, batch 4096, %d steps timed (%.0f ms/step)" % (n4k, ps4k * 1e3)}}
 
 
 def main():
@@ -165,8 +210,10 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bf16_b65536")
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (shard_1m: total rows)")
     ap.add_argument("--timesteps", type=int, default=1000, help="reverse steps per pass (1000 = the metric's T)")
+    ap.add_argument("--condition", action="store_true", help="conditional sampling: a one-row condition repeated to the batch")
+    ap.add_argument("--sampler", choices=["ddpm", "ddim50"], default="ddpm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -185,15 +232,33 @@ def main():
     dtype, batch, config_name = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
-    model = build_model(dtype, dev)
     T = args.timesteps
-    gathered = torch.empty((world * batch, DIMS[2]), device=dev, dtype=torch.float32) if world > 1 else None
+    training = args.workload == "train_dp"
+    model = build_model(dtype, dev, **(dict(max_batch_size=batch, learning_rate=1e-4) if training else {}))
+    cond = ops.philox_normal(1, DIMS[0], SEED, 51, 0, device=dev) if args.condition else None   # [1, 512]: broadcast to the batch
 
-    def one_pass(k):
-        out = model.p_sample_loop((batch, DIMS[2]), seed=SEED + k, row_offset=rank * batch, t_start=999, t_stop=1000 - T)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
-        return out
+    if args.workload == "shard_1m":
+        total = batch
+        first, count = parallel.shard_rows(total, world, rank)
+        scaling = "strong"
+    else:
+        total, first, count, scaling = world * batch, rank * batch, batch, "weak"
+
+    if training:
+        x_train = ops.philox_normal(count, DIMS[0], 7, 52, 0, first, dev)
+        torch.manual_seed(1234)
+
+        def one_pass(k):
+            return model.train_step(x_train, k)
+    else:
+        def one_pass(k):
+            if args.sampler == "ddim50":
+                out = model.ddim_sample_loop((count, DIMS[2]), cond, 50, 0.0, seed=SEED + k, row_offset=first)
+            else:
+                out = model.p_sample_loop((count, DIMS[2]), cond, seed=SEED + k, row_offset=first, t_start=999, t_stop=1000 - T)
+            if world > 1:
+                out = parallel.gather_rows(out, total)
+            return out
 
     for k in range(args.warmup):
         one_pass(-1 - k)
@@ -211,25 +276,51 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    finite = bool(torch.isfinite(out).all().item())
+    finite = bool(np.isfinite(out["loss"])) if training else bool(torch.isfinite(out).all().item())
 
     if rank == 0:
-        main_roof, all_roof, upd_roof, gn_roof = roofline(model, dtype, batch)
-        samples = world * batch * args.steps * (T / 1000.0)
+        # live roofline: per-launch events over a short window of the same work
+        if training:
+            recs, clean_ms, over = timed_window(lambda: model.train_step(x_train, 10 ** 6))
+            roofs = summarize_records(recs, dtype, count, TRAIN_FLOP_PER_SAMPLE, args.workload)
+            samples = total * args.steps
+            metric, sampler_desc = "train samples/sec (noise-prediction loss fwd+bwd + clip + AdamW)", "train_step"
+            per_unit_ms = None
+        else:
+            window = 50 if args.sampler == "ddim50" else 8
+            wb = min(count, 65536)
+            if args.sampler == "ddim50":
+                fn = lambda: model.ddim_sample_loop((wb, DIMS[2]), cond, 50, 0.0, seed=SEED, row_offset=first)
+            else:
+                fn = lambda: model.p_sample_loop((wb, DIMS[2]), cond, seed=SEED, row_offset=first, t_start=999, t_stop=1000 - window)
+            recs, clean_ms, over = timed_window(fn)
+            roofs = summarize_records(recs, dtype, wb * window, ALGO_FLOP_PER_SAMPLE_STEP_COND if args.condition else ALGO_FLOP_PER_SAMPLE_STEP,
+                                      args.workload)
+            nsteps = 50 if args.sampler == "ddim50" else T
+            samples = total * args.steps * (1.0 if args.sampler == "ddim50" else T / 1000.0)
+            metric = "DDPM samples/sec (T=1000)" if args.sampler == "ddpm" else "DDIM-50 samples/sec"
+            sampler_desc = "p_sample_loop (DDPM, linear beta 1e-4..2e-2)" if args.sampler == "ddpm" else "ddim_sample_loop (50 steps, eta 0)"
+            per_unit_ms = round(elapsed / args.steps / nsteps * 1e3, 4)
+        roofs["roofline"]["window"] = {"clean_ms": round(clean_ms, 4), "launches": len(recs), "per_event_cost_us": round(over * 1e3, 2)}
         line = {
-            "metric": "DDPM samples/sec (T=1000)", "value": round(samples / elapsed, 2), "unit": "samples/s",
+            "metric": metric, "value": round(samples / elapsed, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": config_name, "denoiser": "emb 512 / hidden 256 / 44.3M params", "per_gpu_batch": batch,
-                       "global_batch": world * batch, "timesteps": T, "sampler": "p_sample_loop (DDPM, linear beta 1e-4..2e-2)",
-                       "parallelism": "rows sharded over %d GPU(s), RCCL all-gather of latents" % world,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": config_name, "workload_name": args.workload, "denoiser": "emb 512 / hidden 256 / 44.3M params",
+                       "per_gpu_batch": count, "global_batch": total, "timesteps": T, "sampler": sampler_desc, "sampler_name": args.sampler,
+                       "condition": bool(args.condition),
+                       "parallelism": ("rows sharded over %d GPU(s), RCCL all-gather of latents" % world) if not training else
+                                      ("data parallel over %d GPU(s), RCCL all-reduce of the gradient arena" % world),
                        "weights": "random (counter RNG, xavier variance), no checkpoint ships"},
-            "roofline": main_roof, "roofline_all_gemms": all_roof, "roofline_schedule_update": upd_roof, "groupnorm_kernel": gn_roof,
-            "ms_per_denoise_step": round(elapsed / args.steps / T * 1e3, 4), "outputs_finite": finite,
+            "outputs_finite": finite,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        line.update(roofs)
+        if per_unit_ms is not None:
+            line["ms_per_denoise_step"] = per_unit_ms
+        if world == 1 and not args.no_cpu_baseline and not training:
             line["cpu_baseline"] = cpu_baseline({k: v.detach().cpu().numpy() for k, v in model.model.state_dict().items()})
-            line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+            if args.sampler == "ddpm":
+                line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -16,7 +16,7 @@
  *   - every call only enqueues work on the given stream (a hipStream_t passed as void*, NULL =
  *     the null stream) and returns without synchronising;
  *   - ADCDIFF_F32 computes with float32 operands on v_mfma_f32_32x32x2_f32, ADCDIFF_BF16 with
- *     bfloat16 operands on v_mfma_f32_32x32x16_bf16; accumulation, GroupNorm statistics, the
+ *     bfloat16 operands on v_mfma_f32_16x16x32_bf16; accumulation, GroupNorm statistics, the
  *     latent x_t and the schedule update are float32 in both.
  */
 #ifndef ADCDIFF_H
@@ -284,14 +284,15 @@ int adcdiff_clip_adamw_step(const adcdiff_opt_tensor* tensors, int n_tensors, lo
 /* ------------------------------------------------------------------ measurement ------ */
 
 /* Per-launch timing for benchmarks; no counterpart in the reference.  Between adcdiff_timing_begin and
- * adcdiff_timing_end every GEMM, GroupNorm+SiLU and schedule-update launch made through this library is
- * bracketed by a pair of hipEvents on the stream it is launched on (up to max_records launches; later
- * ones are not recorded).  adcdiff_timing_end synchronises those events and returns one record per
- * launch; ms is the event-pair time minus the median time of nine empty event pairs recorded on the same
- * stream at the end (what the two events cost by themselves, ~10-30 us).  Not thread safe; not for use under
- * graph capture. */
+ * adcdiff_timing_end every GEMM, GroupNorm+SiLU and schedule-update launch made through this library has a
+ * hipEvent recorded in front of it on the stream it is launched on (up to max_records launches; later ones
+ * are not recorded); adcdiff_timing_end records one more event behind the last launch, synchronises it and
+ * returns one record per launch whose ms is the span from its event to the next launch's event.  The records
+ * of a window therefore add up to the window's device time; the dispatch gap behind a kernel (1-2 us) is charged
+ * to it.  All launches of a window must go to ONE stream.  Not thread safe; not for use under graph capture. */
 enum { ADCDIFF_KIND_GEMM_F32 = 0, ADCDIFF_KIND_GEMM_BF16 = 1, ADCDIFF_KIND_GROUPNORM = 2, ADCDIFF_KIND_UPDATE = 3,
-       ADCDIFF_KIND_GEMM_BF16_T256 = 4 /* bf16 GEMM that ran on the 256 x 256-tile kernel */ };
+       ADCDIFF_KIND_GEMM_BF16_T256 = 4 /* bf16 GEMM that ran on the 256 x 256-tile kernel */,
+       ADCDIFF_KIND_OTHER = 5 /* every other kernel launch of the library (casts, transposes, backward element-wise kernels, optimizer) */ };
 typedef struct adcdiff_timing_record {
     int kind;
     int M, N, K;        /* GEMM: rows, outputs, total K; others: rows, columns, 0 */

@@ -61,6 +61,41 @@ for k, d in traffic.items():
     if fetch is not None and write is not None:
         entry["hbm_bytes_per_launch"] = (2.0 * fetch + write) * 1024.0
     out["kernels"][k] = entry
+# matrix-core counters: per kernel, sums over the dispatches of the pass, joined with the dispatch durations of the same pass
+mf = one("pmc_mfma/**/*counter_collection.csv")
+if mf:
+    agg = {}
+    seen = set()
+    for r in csv.DictReader(open(mf)):
+        k = short(r["Kernel_Name"])
+        a = agg.setdefault(k, {"dispatches": 0, "ns": 0.0})
+        a[r["Counter_Name"]] = a.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        did = r.get("Dispatch_Id")
+        if did not in seen:
+            seen.add(did)
+            a["dispatches"] += 1
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                a["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    mfma = {}
+    for k, a in agg.items():
+        busy = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        if busy <= 0:
+            continue
+        e = {"dispatches": a["dispatches"], "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_WAVE_CYCLES": a.get("SQ_WAVE_CYCLES"),
+             "SQ_WAIT_ANY": a.get("SQ_WAIT_ANY"), "SQ_WAIT_INST_ANY": a.get("SQ_WAIT_INST_ANY"),
+             "SQ_VALU_MFMA_COEXEC_CYCLES": a.get("SQ_VALU_MFMA_COEXEC_CYCLES"),
+             "mfma_mops_bf16": a.get("SQ_INSTS_VALU_MFMA_MOPS_BF16"), "mfma_mops_f32": a.get("SQ_INSTS_VALU_MFMA_MOPS_F32")}
+        if a["ns"] > 0:
+            # busy cycles summed over the chip's 1024 SIMDs against the kernel's wall time: the clock-equivalent each SIMD's matrix pipe
+            # was busy at, and that as a fraction of the 2.4 GHz the dense peak is quoted at
+            ghz = busy / 1024.0 / a["ns"]
+            e["mfma_busy_ghz_per_simd"] = ghz
+            e["mfma_busy_frac_of_2p4ghz"] = ghz / 2.4
+            e["avg_dispatch_us_under_counters"] = a["ns"] / a["dispatches"] / 1e3
+        mfma[k] = e
+    out["mfma_counters"] = {"note": "rocprofv3 --pmc pass of its own (profiled clocks run a few per cent lower than unprofiled ones); "
+                                    "SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles per wave",
+                            "kernels": mfma}
 line = os.path.join(src, "bench_line.json")
 if os.path.exists(line) and os.path.getsize(line):
     out["bench_line_under_profiler"] = json.loads(open(line).read().strip().splitlines()[-1])

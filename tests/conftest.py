@@ -62,3 +62,18 @@ def check_loop(out, ref, dtype, what=""):
     gate = LOOP_GATE[dtype]
     print("parity %s %s: per-element max %.3e  99.9%% %.3e  row-scaled %.3e" % (what, dtype, mx, p999, rs))
     assert mx <= gate["elem_max"] and p999 <= gate["elem_p999"] and rs <= gate["row_scaled"], (what, dtype, mx, p999, rs)
+
+
+@pytest.fixture(scope="session")
+def golden_tiny():
+    return load_golden("tiny")
+
+
+@pytest.fixture(scope="session")
+def golden_a():
+    return load_golden("config_a")
+
+
+@pytest.fixture(scope="session")
+def golden_b():
+    return load_golden("config_b")

@@ -254,3 +254,27 @@ def test_split_k_partials_sum_to_the_unsplit_product(dtype, tol, M, N, K, S):
         assert torch.equal(one, parts[s_])
     with pytest.raises(Exception, match="split_k"):
         ops.gemm([a], w, dtype=dtype, split_k=S, bias=torch.zeros(N, device="cuda"))
+
+
+def test_custom_operators_through_the_dispatcher():
+    """torch.ops.adcdiff.*: called directly (not through the python wrappers), results equal the raw C-ABI calls bit for bit, and
+    torch.library.opcheck accepts schema, fake-tensor rule and dispatch registration of the operators."""
+    rng = np.random.default_rng(3)
+    x, eps = _t(rng.standard_normal((96, 128)).astype(np.float32)), _t(rng.standard_normal((96, 128)).astype(np.float32))
+    coef = (1.01, 0.02, 0.7, 0.1)
+    a = torch.ops.adcdiff.ddpm_step(x, eps, None, *coef, 2025, 17, 5)
+    b = ops._raw_ddpm_step(x, eps, coef, seed=2025, step=17, row_offset=5)
+    assert torch.equal(a, b)
+    z = torch.ops.adcdiff.philox_normal(96, 128, 2025, philox.STREAM_STEP, 17, 5, torch.device(DEV))
+    assert torch.equal(torch.ops.adcdiff.ddpm_step(x, eps, z, *coef, 0, 0, 0), a)      # injected noise == in-kernel noise of the same counters
+    s = torch.ops.adcdiff.latent_summary(x)
+    assert np.array_equal(s.cpu().numpy()[:, 1], x.cpu().numpy().sum(axis=1, dtype=np.float32))
+    W = _t((rng.standard_normal((128, 128)) / 11.0).astype(np.float32))
+    A = torch.zeros(128, 128, device=DEV)
+    A[:96] = x
+    y, = torch.ops.adcdiff.gemm([A], W, None, None, None, None, 0, True, False, [], [], [], 96, 0, 1e-5, 0, 0)
+    assert rel_err(y[:96].cpu().numpy(), x.cpu().numpy() @ W.cpu().numpy().T) < 2e-6
+    torch.library.opcheck(torch.ops.adcdiff.ddpm_step, (x, eps, None, *coef, 2025, 17, 5))
+    torch.library.opcheck(torch.ops.adcdiff.latent_summary, (x,))
+    # all 128 rows valid here: rows beyond m_valid are never written, so their (uninitialised) contents differ between two calls
+    torch.library.opcheck(torch.ops.adcdiff.gemm, ([A], W, None, None, None, None, 0, True, False, [], [], [], 0, 0, 1e-5, 0, 0))
