@@ -77,6 +77,7 @@ class AdamWArgs(C.Structure):
 
 
 OPT_CHUNK = 4096
+OPT_NOALLOC_MAX_CHUNKS = 65536
 KIND_GEMM_F32, KIND_GEMM_BF16, KIND_GROUPNORM, KIND_UPDATE, KIND_GEMM_BF16_T256, KIND_OTHER = 0, 1, 2, 3, 4, 5
 
 # name -> (restype, argtypes): every symbol include/adcdiff.h declares
@@ -113,6 +114,7 @@ SIGNATURES = {
     "adcdiff_latent_summary": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp]),
     "adcdiff_clip_adamw_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "adcdiff_clip_adamw_step": (C.c_int, [c_fp, C.c_int, C.c_longlong, C.POINTER(AdamWArgs), c_fp, c_fp, C.c_size_t, c_fp]),
+    "adcdiff_clip_adamw_step_noalloc": (C.c_int, [c_fp, C.c_int, C.c_longlong, C.POINTER(AdamWArgs), c_fp, c_fp]),
     "adcdiff_timing_begin": (C.c_int, [C.c_int]),
     "adcdiff_timing_end": (C.c_int, [C.POINTER(TimingRecord), C.c_int, C.POINTER(C.c_int)]),
 }

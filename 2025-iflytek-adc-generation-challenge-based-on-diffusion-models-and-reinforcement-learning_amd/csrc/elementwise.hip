@@ -3,6 +3,7 @@
 // Built with -ffp-contract=off so that the update formulas round exactly like the reference's
 // separate float32 torch ops.
 #include <cmath>
+#include <mutex>
 
 #include "common.h"
 
@@ -617,6 +618,33 @@ static int clip_adamw_check(const char* who, const adcdiff_opt_tensor* tensors, 
     return ADCDIFF_OK;
 }
 
+// Scratch of the entry point that allocates nothing: 64 scalars + one partial sum per chunk, in the code object's own
+// device memory (every GPU the library runs on holds its copy until the process ends).
+static __device__ __align__(256) float scratch[64 + ADCDIFF_OPT_NOALLOC_MAX_CHUNKS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+float* g_scratch_ptr[kMaxDevices] = {};   // device address of `scratch` on each device, looked up on first use
+}  // namespace
+
+// Device address of this device's copy of `scratch` (the array's name is only a host-side handle for the lookup).
+static int scratch_for_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "clip_adamw_step_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return fail(ADCDIFF_E_BADARG, "clip_adamw_step_noalloc: device %d outside 0..%d", dev, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float* ptr = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return fail(ADCDIFF_E_LAUNCH, "clip_adamw_step_noalloc: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return ADCDIFF_OK;
+}
+
 }  // namespace adcdiff
 
 extern "C" int adcdiff_clip_adamw_step(const adcdiff_opt_tensor* tensors, int n_tensors, long long total_chunks, const adcdiff_adamw_args* a,
@@ -627,6 +655,19 @@ extern "C" int adcdiff_clip_adamw_step(const adcdiff_opt_tensor* tensors, int n_
         return fail(ADCDIFF_E_WORKSPACE, "clip_adamw_step: workspace of %zu bytes, %zu needed", workspace_bytes,
                     adcdiff_clip_adamw_workspace_bytes(total_chunks));
     float* scal = reinterpret_cast<float*>(workspace);          // [0] norm, [1] clip factor
+    return clip_adamw_launch(tensors, n_tensors, total_chunks, a, grad_norm, scal, scal + 64, as_stream(stream_));
+}
+
+extern "C" int adcdiff_clip_adamw_step_noalloc(const adcdiff_opt_tensor* tensors, int n_tensors, long long total_chunks,
+                                               const adcdiff_adamw_args* a, float* grad_norm, adcdiff_stream_t stream_) {
+    using namespace adcdiff;
+    TRY_RC(clip_adamw_check("clip_adamw_step_noalloc", tensors, n_tensors, total_chunks, a));
+    if (total_chunks > ADCDIFF_OPT_NOALLOC_MAX_CHUNKS)
+        return fail(ADCDIFF_E_WORKSPACE, "clip_adamw_step_noalloc: %lld chunks exceed the built-in scratch of %d chunks (%d parameters); use "
+                    "adcdiff_clip_adamw_step with a workspace", total_chunks, ADCDIFF_OPT_NOALLOC_MAX_CHUNKS,
+                    ADCDIFF_OPT_NOALLOC_MAX_CHUNKS * ADCDIFF_OPT_CHUNK);
+    float* scal = nullptr;
+    TRY_RC(scratch_for_current_device(&scal));
     return clip_adamw_launch(tensors, n_tensors, total_chunks, a, grad_norm, scal, scal + 64, as_stream(stream_));
 }
 

@@ -281,6 +281,18 @@ size_t adcdiff_clip_adamw_workspace_bytes(long long total_chunks);
 int adcdiff_clip_adamw_step(const adcdiff_opt_tensor* tensors, int n_tensors, long long total_chunks, const adcdiff_adamw_args* args,
                             float* grad_norm, void* workspace, size_t workspace_bytes, adcdiff_stream_t stream);
 
+/* adcdiff_clip_adamw_step for callers that cannot allocate (code under HIP graph capture, serving loops, harnesses that forbid
+ * hipMalloc); it has no counterpart in the reference.  Same arguments and results, but no workspace: the per-chunk partial sums
+ * and the (norm, clip) scalars live in a fixed array inside the library's code object, 64 + ADCDIFF_OPT_NOALLOC_MAX_CHUNKS
+ * floats (256.25 KiB) that every GPU the library runs on holds until the process ends.  Limit: total_chunks <=
+ * ADCDIFF_OPT_NOALLOC_MAX_CHUNKS (268 M parameters; the 44.3 M-parameter denoiser has 10 880); more is rejected with
+ * ADCDIFF_E_WORKSPACE.  Calls no hipMalloc / hipFree and no allocating library routine; the first call on a device looks
+ * the array's address up (hipGetSymbolAddress).  All calls on one GPU share that array: calls that overlap on one GPU (two
+ * streams, two threads) race; calls on one stream are ordered by the stream.  Nothing in it needs clearing between calls. */
+#define ADCDIFF_OPT_NOALLOC_MAX_CHUNKS 65536
+int adcdiff_clip_adamw_step_noalloc(const adcdiff_opt_tensor* tensors, int n_tensors, long long total_chunks,
+                                    const adcdiff_adamw_args* args, float* grad_norm, adcdiff_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement ------ */
 
 /* Per-launch timing for benchmarks; no counterpart in the reference.  Between adcdiff_timing_begin and
