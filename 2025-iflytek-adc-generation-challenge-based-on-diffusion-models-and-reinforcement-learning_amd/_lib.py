@@ -15,13 +15,18 @@ class GnOut(C.Structure):
     _fields_ = [("gamma", c_fp), ("beta", c_fp), ("out", c_fp), ("ldo", C.c_int), ("group_size", C.c_int)]
 
 
+class StepUpdate(C.Structure):
+    _fields_ = [("kind", C.c_int), ("c", C.c_float * 5), ("x", c_fp), ("ldx", C.c_int), ("noise", c_fp), ("ldn", C.c_int),
+                ("seed", C.c_uint64), ("step", C.c_uint32), ("row_offset", C.c_uint64)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("m_valid", C.c_int), ("nseg", C.c_int),
                 ("A", c_fp * 3), ("lda", C.c_int * 3), ("K", C.c_int * 3), ("W", c_fp), ("ldw", C.c_int),
                 ("bias", c_fp), ("rowbias", c_fp), ("ldrb", C.c_longlong), ("rowbias_idx", c_fp), ("rowbias_rows", C.c_int),
                 ("residual", c_fp), ("ldr", C.c_int), ("act", C.c_int), ("out_f32", c_fp), ("ldo_f32", C.c_int),
                 ("out_op", c_fp), ("ldo_op", C.c_int), ("n_gn", C.c_int), ("gn", GnOut * 2), ("gn_eps", C.c_float), ("tile_hint", C.c_int),
-                ("split_k", C.c_int), ("split_stride", C.c_longlong)]
+                ("split_k", C.c_int), ("split_stride", C.c_longlong), ("update", StepUpdate)]
 
 
 class DdpmCoef(C.Structure):
@@ -139,8 +144,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.adcdiff_abi_version() != 1:
-        raise AdcdiffError("libadcdiff.so has ABI version %d, expected 1" % lib.adcdiff_abi_version())
+    if lib.adcdiff_abi_version() != 2:
+        raise AdcdiffError("libadcdiff.so has ABI version %d, expected 2" % lib.adcdiff_abi_version())
     _lib = lib
     return lib
 

@@ -55,6 +55,7 @@ struct GemmParams {
     int n_gn;
     GnOut gn[2];
     float eps;
+    adcdiff_step_update upd;     // schedule update applied to v before the outputs (kind 0 = none)
     int ksplit;                  // grid.y: K slices (1 without split-K)
     long long split_k_bytes;     // byte offset along K of slice blockIdx.y (0 without split-K)
     long long split_out_stride;  // floats between the partial outputs of consecutive slices
@@ -288,6 +289,42 @@ struct Epilogue {
         }
     }
 
+    // v = predicted noise of 8 contiguous columns of row `row` -> the latent after the reverse step (see adcdiff_step_update).
+    // Same expressions, in the same order and without fma contraction, as ddpm_step_kernel / ddim_step_kernel.
+    static __device__ __forceinline__ void apply_update(const adcdiff_step_update& u, float (&v)[8], long row, long col) {
+#pragma clang fp contract(off)
+        float x[8], z[8];
+        load8(u.x + row * u.ldx + col, x);
+        const float sigma = u.kind == 1 ? u.c[3] : u.c[4];
+        if (sigma != 0.0f) {
+            if (u.noise) {
+                load8(u.noise + row * u.ldn + col, z);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 q = philox_normal4(u.seed, ADCDIFF_STREAM_STEP, u.step, u.row_offset + (uint64_t)row, (uint32_t)(col >> 2) + h);
+                    z[4 * h] = q[0]; z[4 * h + 1] = q[1]; z[4 * h + 2] = q[2]; z[4 * h + 3] = q[3];
+                }
+            }
+        }
+        if (u.kind == 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float o = u.c[0] * (x[k] - (u.c[1] * v[k]) / u.c[2]);
+                if (sigma != 0.0f) o = o + sigma * z[k];
+                v[k] = o;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float dir = u.c[3] * v[k];
+                if (sigma != 0.0f) dir = dir + sigma * z[k];
+                const float pred_x0 = (x[k] - u.c[0] * v[k]) / u.c[1];
+                v[k] = u.c[2] * pred_x0 + dir;
+            }
+        }
+    }
+
     // One step: RPS rows of the staged chunk, a lane owning 8 contiguous columns of one row.
     template <bool PRM_IN_REGS>
     static __device__ __forceinline__ void step(const GemmParams& p, const float* stage, const float* prm, float* xch_base, int h, int st,
@@ -329,6 +366,7 @@ struct Epilogue {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = silu_f(v[k]);
         }
+        if (p.upd.kind != 0) apply_update(p.upd, v, lrow, col);
         if (p.out_f32 && live) store8<float>(p.out_f32 + (long)blockIdx.y * p.split_out_stride + row * p.ldo_f32 + col, v);
         if (p.out_op && live) store8<T>(reinterpret_cast<T*>(p.out_op) + row * p.ldo_op + col, v);
         float* const xch = xch_base + (step_id & 1) * (2 * XB);
@@ -1081,6 +1119,14 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     p.bias = a.bias; p.rowbias = a.rowbias; p.ldrb = a.ldrb; p.rowbias_idx = a.rowbias_idx;
     p.rowbias_rows = a.rowbias_idx ? a.rowbias_rows : 0;
     p.residual = a.residual; p.ldr = a.ldr; p.act = a.act;
+    p.upd = a.update;
+    if (a.update.kind != 0) {
+        const adcdiff_step_update& u = a.update;
+        if (u.kind != 1 && u.kind != 2) return fail(ADCDIFF_E_BADARG, "gemm: update kind %d (1 = DDPM, 2 = DDIM)", u.kind);
+        if (a.act || a.split_k > 1) return fail(ADCDIFF_E_BADARG, "gemm: the schedule update is not combined with act or split_k");
+        if (!u.x || !aligned16(u.x) || u.ldx < a.N || u.ldx % 4 != 0 || (u.noise && (!aligned16(u.noise) || u.ldn < a.N || u.ldn % 4 != 0)))
+            return fail(ADCDIFF_E_BADARG, "gemm: update: x / noise null, misaligned or leading dimension < N");
+    }
     p.out_f32 = a.out_f32; p.ldo_f32 = a.ldo_f32;
     p.out_op = a.out_op; p.ldo_op = a.ldo_op;
     const double esz = esize;

@@ -39,6 +39,7 @@ int adcdiff::plan_dims(adcdiff_unet* n, int input_dim, int hidden_dim, int outpu
         if (i > 0) n->fused = n->fused && fusable(b.gs1, n->blk[i - 1].cout);           // applied by the previous block
         if (i >= 6) n->fused = n->fused && fusable(b.gs1, n->blk[9 - i].cout);          // and by the skip's encoder block
     }
+    n->fold = n->fused && input_dim == output_dim && fusable(n->blk[0].gs1, output_dim);
     return ADCDIFF_OK;
 }
 
@@ -294,8 +295,18 @@ struct Act {
     int C;
 };
 
+// A sampling loop's step folded into the forward: the output GEMM applies the schedule update to the latent in place (the
+// predicted noise is never stored) and writes what encoder.0 reads in the NEXT step -- the latent in the operand type and
+// SiLU(GroupNorm1(latent)) -- into the same workspace slots this step read them from.  Consecutive steps carve the
+// workspace identically, so from the second step on the stand-alone GroupNorm is not launched (have_in).
+struct StepFold {
+    adcdiff_step_update upd;
+    float* x_out;    // = x of the forward
+    bool have_in;
+};
+
 int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform, const float* cemb,
-                  int ldce, float* eps, int lde, Bump& ws, bool dry, hipStream_t st) {
+                  int ldce, float* eps, int lde, Bump& ws, bool dry, hipStream_t st, const StepFold* fold = nullptr) {
     const int Bp = (int)round_up((size_t)B, 128);
     const size_t e = (size_t)n->esz;
     const int H = n->H, dt = n->dtype;
@@ -310,11 +321,12 @@ int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t
     }
     // the latent enters through the one stand-alone GroupNorm of the step: encoder.0's norm1 (diffusion_model.py:888-889)
     Act in;
+    void *in_nrm, *in_raw;
     {
         const BlockPlan& b0 = n->blk[0];
-        void* nrm = ws.take((size_t)Bp * n->D * e);
-        void* raw = ws.take((size_t)Bp * n->D * e);
-        if (!dry) TRY(groupnorm_silu(x, ldx, B, n->D, b0.g1, p.blocks[0].norm1_w, p.blocks[0].norm1_b, 1e-5f, dt, nrm, n->D, raw, n->D, st));
+        void* nrm = in_nrm = ws.take((size_t)Bp * n->D * e);
+        void* raw = in_raw = ws.take((size_t)Bp * n->D * e);
+        if (!dry && !(fold && fold->have_in)) TRY(groupnorm_silu(x, ldx, B, n->D, b0.g1, p.blocks[0].norm1_w, p.blocks[0].norm1_b, 1e-5f, dt, nrm, n->D, raw, n->D, st));
         in = Act{raw, nrm, nullptr, n->D};
     }
     Act outs[10];
@@ -376,10 +388,24 @@ int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t
     if (!dry) {   // output head (diffusion_model.py:786-788): its GroupNorm + SiLU was applied by decoder.3's GEMM
         adcdiff_gemm_args g = gemm_args(dt, Bp, B, n->O);
         g.nseg = 1; g.A[0] = outs[9].n_next; g.lda[0] = H; g.K[0] = H; g.W = n->w_out; g.ldw = H; g.bias = p.out_b;
-        g.out_f32 = eps; g.ldo_f32 = lde;
+        if (fold) {
+            g.update = fold->upd;
+            g.out_f32 = fold->x_out; g.ldo_f32 = ldx;
+            g.out_op = in_raw; g.ldo_op = n->D;
+            g.n_gn = 1; g.gn_eps = 1e-5f;
+            g.gn[0] = adcdiff_gn_out{p.blocks[0].norm1_w, p.blocks[0].norm1_b, in_nrm, n->D, n->blk[0].gs1};
+        } else {
+            g.out_f32 = eps; g.ldo_f32 = lde;
+        }
         TRY(gemm_dispatch(g, st));
     }
     return ADCDIFF_OK;
+}
+
+// measurement aid: ADCDIFF_NO_FOLD=1 keeps the sampler's update and encoder.0's GroupNorm as launches of their own
+bool fold_enabled() {
+    static const bool on = [] { const char* e = getenv("ADCDIFF_NO_FOLD"); return !(e && atoi(e) != 0); }();
+    return on;
 }
 
 int forward_impl(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform, const float* cemb,
@@ -458,8 +484,18 @@ extern "C" int adcdiff_ddpm_sample_loop(adcdiff_unet* n, float* x, int ldx, int 
     for (int t = t_start; t >= t_stop; --t) {
         Bump ws(workspace, workspace_bytes);
         float* eps = (float*)ws.take((size_t)Bp * n->O * 4);
-        TRY(forward_impl(n, x, ldx, B, nullptr, t, cemb, ldce, eps, n->O, ws, false, as_stream(stream_)));
         const float* nz = noise ? noise + (size_t)(t_start - t) * (size_t)noise_step_stride : nullptr;
+        if (n->fold && fold_enabled()) {
+            StepFold f{};
+            f.upd.kind = 1;
+            f.upd.c[0] = coef[t].sqrt_recip_alpha; f.upd.c[1] = coef[t].beta; f.upd.c[2] = coef[t].sqrt_one_minus_ac; f.upd.c[3] = coef[t].sigma;
+            f.upd.x = x; f.upd.ldx = ldx; f.upd.noise = nz; f.upd.ldn = n->O;
+            f.upd.seed = seed; f.upd.step = (uint32_t)t; f.upd.row_offset = row_offset;
+            f.x_out = x; f.have_in = t != t_start;
+            TRY(forward_fused(n, x, ldx, B, nullptr, t, cemb, ldce, nullptr, 0, ws, false, as_stream(stream_), &f));
+            continue;
+        }
+        TRY(forward_impl(n, x, ldx, B, nullptr, t, cemb, ldce, eps, n->O, ws, false, as_stream(stream_)));
         TRY(adcdiff_ddpm_step(x, ldx, eps, n->O, nz, n->O, x, ldx, B, n->O, coef[t], seed, (uint32_t)t, row_offset, stream_));
     }
     return ADCDIFF_OK;
@@ -479,8 +515,19 @@ extern "C" int adcdiff_ddim_sample_loop(adcdiff_unet* n, float* x, int ldx, int 
         if (t < 0 || t >= n->T) return fail(ADCDIFF_E_BADARG, "ddim_sample_loop: timestep %d outside 0..%d", t, n->T - 1);
         Bump ws(workspace, workspace_bytes);
         float* eps = (float*)ws.take((size_t)Bp * n->O * 4);
-        TRY(forward_impl(n, x, ldx, B, nullptr, t, cemb, ldce, eps, n->O, ws, false, as_stream(stream_)));
         const float* nz = noise ? noise + (size_t)i * (size_t)noise_step_stride : nullptr;
+        if (n->fold && fold_enabled()) {
+            StepFold f{};
+            f.upd.kind = 2;
+            f.upd.c[0] = coef[i].c_eps; f.upd.c[1] = coef[i].sqrt_ac_t; f.upd.c[2] = coef[i].sqrt_ac_prev; f.upd.c[3] = coef[i].dir_coef;
+            f.upd.c[4] = coef[i].sigma;
+            f.upd.x = x; f.upd.ldx = ldx; f.upd.noise = nz; f.upd.ldn = n->O;
+            f.upd.seed = seed; f.upd.step = (uint32_t)t; f.upd.row_offset = row_offset;
+            f.x_out = x; f.have_in = i != 0;
+            TRY(forward_fused(n, x, ldx, B, nullptr, t, cemb, ldce, nullptr, 0, ws, false, as_stream(stream_), &f));
+            continue;
+        }
+        TRY(forward_impl(n, x, ldx, B, nullptr, t, cemb, ldce, eps, n->O, ws, false, as_stream(stream_)));
         TRY(adcdiff_ddim_step(x, ldx, eps, n->O, nz, n->O, x, ldx, B, n->O, coef[i], seed, (uint32_t)t, row_offset, stream_));
     }
     return ADCDIFF_OK;

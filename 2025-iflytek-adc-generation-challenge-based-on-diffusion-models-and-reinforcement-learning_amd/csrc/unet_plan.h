@@ -80,6 +80,7 @@ struct adcdiff_unet {
     size_t arena_used;
     bool packed;
     bool fused;     // every GroupNorm can be applied in a producing GEMM's epilogue
+    bool fold;      // fused, and the output GEMM can apply the sampler's update and encoder.0's norm1 of the next step
     adcdiff::Tape tape;
 };
 

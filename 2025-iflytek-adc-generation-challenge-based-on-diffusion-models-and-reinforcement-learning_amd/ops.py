@@ -51,13 +51,15 @@ def _operand(x, code):
 
 
 def _raw_gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, act=0, out_f32=True, out_op=False, gn=(),
-         m_valid=None, dtype="fp32", eps=1e-5, tile_hint=0, split_k=0):
+         m_valid=None, dtype="fp32", eps=1e-5, tile_hint=0, split_k=0, update=None):
     """adcdiff_gemm: v = [A0|A1|A2] @ w.T + bias + rowbias + residual.
 
     a_list: operand tensors [M, K_s] (M a multiple of 128) already in the operand dtype; w [N, sum K_s]; residual in the
     operand dtype; gn: up to two (gamma, beta, group_size) for fused SiLU(GroupNorm(v)) outputs in the operand dtype.
     split_k = S > 1: K is cut into S slices computed by separate workgroups; the float32 result then has shape [S, M, N]
     (the slices' partial products, to be summed by the caller).
+    update = dict(kind=1 | 2, c=coefficients, x=latent [M, N] float32, noise=None | [M, N], seed, step, row_offset): the
+    sampler's reverse step applied to v before the outputs are formed (adcdiff_step_update in include/adcdiff.h).
     Returns the requested outputs in the order (v float32, v operand type, gn outputs...), a single tensor if only one."""
     lib = _lib.load()
     code = dtype_code(dtype)
@@ -82,9 +84,11 @@ def _raw_gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=Non
     args.act = act
     args.tile_hint = tile_hint
     outs = []
-    if out_f32:
-        o = torch.empty((split_k, M, N) if split_k > 1 else (M, N), device=w.device, dtype=torch.float32)
-        args.out_f32, args.ldo_f32 = o.data_ptr(), N
+    if out_f32 is not None and out_f32 is not False:
+        # a tensor is written in place (the latent of a fused schedule update)
+        o = out_f32 if torch.is_tensor(out_f32) else \
+            torch.empty((split_k, M, N) if split_k > 1 else (M, N), device=w.device, dtype=torch.float32)
+        args.out_f32, args.ldo_f32 = o.data_ptr(), (o.stride(0) if torch.is_tensor(out_f32) else N)
         args.split_k, args.split_stride = int(split_k), M * N
         outs.append(o)
     if out_op:
@@ -100,6 +104,17 @@ def _raw_gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=Non
         args.gn[i].gamma, args.gn[i].beta, args.gn[i].out, args.gn[i].ldo, args.gn[i].group_size = \
             gamma.data_ptr(), beta.data_ptr(), o.data_ptr(), N, int(gs)
         outs.append(o)
+    if update is not None:
+        u = args.update
+        u.kind = int(update["kind"])
+        for i, cv in enumerate(update["c"]):
+            u.c[i] = float(cv)
+        ux, un = update["x"], update.get("noise")
+        _need_gpu(ux)
+        u.x, u.ldx = ux.data_ptr(), ux.stride(0)
+        if un is not None:
+            u.noise, u.ldn = un.data_ptr(), un.stride(0)
+        u.seed, u.step, u.row_offset = int(update.get("seed", 0)), int(update.get("step", 0)), int(update.get("row_offset", 0))
     check(lib.adcdiff_gemm(C.byref(args), _stream()))
     return outs[0] if len(outs) == 1 else tuple(outs)
 

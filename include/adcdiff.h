@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ADCDIFF_ABI_VERSION 1
+#define ADCDIFF_ABI_VERSION 2
 
 enum { ADCDIFF_OK = 0, ADCDIFF_E_BADARG = -1, ADCDIFF_E_LAUNCH = -2, ADCDIFF_E_ARCH = -3, ADCDIFF_E_WORKSPACE = -4 };
 enum { ADCDIFF_F32 = 0, ADCDIFF_BF16 = 1 };
@@ -62,6 +62,26 @@ typedef struct adcdiff_gn_out {
     int ldo;
     int group_size;            /* channels per group: a power of two, 4..128 (4..64 when N % 128 != 0), dividing N */
 } adcdiff_gn_out;
+
+/* Schedule update applied to v in the GEMM's epilogue, before any output is formed: the denoiser's output layer (whose v is
+ * the predicted noise, diffusion_model.py:788) can apply the reverse step of p_sample (:207-216) or ddim_step (:350-369) to the
+ * latent itself, so that the predicted noise never goes to memory and the step's outputs are what the NEXT step reads:
+ *   kind 1 (DDPM): v <- c[0] * (x - c[1] * v / c[2]) + c[3] * z          c = sqrt_recip_alpha, beta, sqrt_one_minus_ac, sigma
+ *   kind 2 (DDIM): v <- c[2] * ((x - c[0] * v) / c[1]) + (c[3] * v + c[4] * z)   c = c_eps, sqrt_ac_t, sqrt_ac_prev, dir_coef, sigma
+ * in the operation order of adcdiff_ddpm_step / adcdiff_ddim_step (bit-identical results); x [M, ldx] float32 is read per row
+ * (out_f32 may alias it: a row's elements are read before they are written); z = noise[r, c] when noise != NULL, else Philox
+ * (seed, ADCDIFF_STREAM_STEP, step, row_offset + r); c[sigma] == 0 draws nothing.  Not combined with act, split_k. */
+typedef struct adcdiff_step_update {
+    int kind;
+    float c[5];
+    const float* x;
+    int ldx;
+    const float* noise;
+    int ldn;
+    uint64_t seed;
+    uint32_t step;
+    uint64_t row_offset;
+} adcdiff_step_update;
 
 typedef struct adcdiff_gemm_args {
     int dtype;                 /* operand type of A, W, residual, out_op and gn outputs: ADCDIFF_F32 / ADCDIFF_BF16 */
@@ -99,6 +119,7 @@ typedef struct adcdiff_gemm_args {
                                   weight-gradient GEMMs (K = batch) whose M x N gives too few tiles to fill the chip.  Only with
                                   out_f32 as the sole output and no bias / rowbias / residual / act. */
     long long split_stride;    /* floats between consecutive partial outputs */
+    adcdiff_step_update update;/* kind 0 = none; see adcdiff_step_update */
 } adcdiff_gemm_args;
 int adcdiff_gemm(const adcdiff_gemm_args* args, adcdiff_stream_t stream);
 

@@ -28,10 +28,27 @@ __device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_
                  : "memory");
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// The same 1 KiB copy through the buffer path: wave-uniform descriptor + scalar byte offset + per-lane 32-bit offset.
+__device__ __forceinline__ void blds16_untracked(i32x4 srd, unsigned voff, unsigned soff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :
+                 : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr)
+                 : "memory");
+}
+
+// M0 written once per step; the pieces address their 1 KiB slots through the instruction's offset field, which shifts the global
+// address too, so the caller's source pointer is pre-shifted by -OFF
+template <int OFF>
+__device__ __forceinline__ void glds16_m0set(const void* gsrc) {
+    asm volatile("global_load_lds_dwordx4 %0, off offset:%1" : : "v"(gsrc), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void set_m0(unsigned v) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(v) : "memory"); }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-enum { ABL_NOREAD = 1, ABL_NODMA = 2, ABL_NOBAR = 4, ABL_NOWAIT = 8, ABL_SAMEK = 16, ABL_SAMETILE = 32, ABL_STAGGER = 64, ABL_STAGGER2 = 128 };
+enum { ABL_NOREAD = 1, ABL_NODMA = 2, ABL_NOBAR = 4, ABL_NOWAIT = 8, ABL_SAMEK = 16, ABL_SAMETILE = 32, ABL_STAGGER = 64, ABL_STAGGER2 = 128, ABL_TAIL = 256, ABL_ASYM = 512, ABL_BUF = 1024, ABL_REG = 2048, ABL_M0ONCE = 4096 };
 
 struct Params {
     const bf16_t* A; const bf16_t* W; bf16_t* C;
@@ -46,7 +63,8 @@ __device__ __forceinline__ int swz(int row) { return (0x78 >> (2 * ((row >> 2) &
 template <int WAVES_N, int ABL, int WAVES_M = 2>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void ring_kernel(const Params p) {
     constexpr int NW = WAVES_M * WAVES_N, WTM = 256 / WAVES_M, WTN = 256 / WAVES_N, TM = WTM / 16, TN = WTN / 16;
-    constexpr int PPW = 32 / NW;            // LDS-DMA pieces per wave and region
+    constexpr bool ASYM = (ABL & ABL_ASYM) != 0;   // only the first four waves issue LDS-DMA (after their MFMAs), 8 pieces each
+    constexpr int PPW = ASYM ? 8 : 32 / NW;        // LDS-DMA pieces per (loading) wave and region
     constexpr int REGION = 32768;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -66,7 +84,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     unsigned dst[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int q = wave * PPW + j;
+        const int q = (ASYM ? (wave & 3) : wave) * PPW + j;
         const bool isA = q < 16;
         const int row = 16 * (q & 15) + prow;
         const int chunk = (lane & 3) ^ swz(row);
@@ -78,14 +96,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
     const int nR = p.K / 32;
     const int wslot = wave % (TM * TN / PPW);                 // every wave its own issue slot inside an 8-MFMA window
     const int wslot2 = ((wave & 3) * 2 + (wave >> 2)) % (TM * TN / PPW);   // SIMD partners (w, w + 4) in adjacent slots
+    const bool loader = !ASYM || wave < 4;
     auto issue = [&](int R) {
-        if (R < nR) {
+        if (loader && R < nR) {
             const unsigned rb = lds0 + (R & 3) * REGION;
 #pragma unroll
             for (int j = 0; j < PPW; ++j) glds16_untracked(src[j] + (long)R * 64, rb + dst[j]);
         }
     };
+    // buffer path: descriptor over this wave's operand (A or W rows of the tile), lane offset without the piece / region part
+    const bool wave_is_a = (ASYM ? (wave & 3) : wave) * PPW < 16;
+    const char* bbase = wave_is_a ? reinterpret_cast<const char*>(p.A) + (long)lm0 * p.K * 2 : reinterpret_cast<const char*>(p.W) + (long)ln0 * p.K * 2;
+    const unsigned long long bb = (unsigned long long)bbase;
+    const i32x4 srd = {__builtin_amdgcn_readfirstlane((int)(unsigned)bb), __builtin_amdgcn_readfirstlane((int)((unsigned)(bb >> 32) & 0xffffu)),
+                       __builtin_amdgcn_readfirstlane((int)(256u * (unsigned)p.K * 2u)), 0x00020000};   // base, stride 0, bytes, raw dword format
+    const unsigned bvoff = (unsigned)prow * (unsigned)(p.K * 2) + (unsigned)(((lane & 3) ^ swz(prow)) * 16);
     auto issue1 = [&](int R, int j) {
+        if (ABL & ABL_BUF) {
+            if (loader && R < nR) {
+                const int q = (ASYM ? (wave & 3) : wave) * PPW + j;
+                blds16_untracked(srd, bvoff, (unsigned)(16 * (q & 15)) * (unsigned)(p.K * 2) + (unsigned)R * 64u, lds0 + (R & 3) * REGION + dst[j]);
+            }
+            return;
+        }
         if (R < nR) glds16_untracked(src[j] + ((ABL & ABL_SAMEK) ? 0L : (long)R * 64), lds0 + (R & 3) * REGION + dst[j]);
     };
 
@@ -107,8 +140,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
                                                          acc[I][J], 0, 0, 0)
 
     // prologue
-    issue(0); issue(1); issue(2); issue(3);
-    {
+    uint4 stg[2][PPW];   // ABL_REG: register staging, two regions in flight
+    issue(0); issue(1);
+    if (!(ABL & ABL_REG)) { issue(2); issue(3); }
+    if (ABL & ABL_REG) wait_vmcnt<0>();
+    else {
         const int inflight = nR - 1 < 3 ? nR - 1 : 3;   // regions allowed to stay in flight so that region 0 has landed
         if (inflight >= 3) wait_vmcnt<3 * PPW>(); else if (inflight == 2) wait_vmcnt<2 * PPW>(); else if (inflight == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
     }
@@ -124,7 +160,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
         for (int j = 0; j < TN; ++j) READ_B(1, smem, j);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {
+    if (ABL & ABL_REG) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < PPW; ++j)
+                if (2 + g < nR) stg[g][j] = *reinterpret_cast<const uint4*>(src[j] + (long)(2 + g) * 64);
+    } else {
         const int inflight = nR - 2 < 2 ? nR - 2 : 2;
         if (inflight >= 2) wait_vmcnt<2 * PPW>(); else if (inflight == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
     }
@@ -148,13 +190,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N / 4) void
                 const int r = x / RD_EVERY;                                                                        \
                 if (r < TN) READ_B((S) ^ 1, rb, r); else READ_A((S) ^ 1, rb, r - TN);                              \
             }                                                                                                      \
+            if (ABL & ABL_M0ONCE) {                                                                               \
+                if (x == 0 && R + 4 < nR) set_m0(lds0 + ((R + 4) & 3) * REGION + dst[0]);                          \
+                if (R + 4 < nR) {                                                                                  \
+                    if (x == 4) glds16_m0set<0>(src[0] + (long)(R + 4) * 64);                                      \
+                    if (x == 12) glds16_m0set<1024>(src[1] + (long)(R + 4) * 64 - 1024);                           \
+                    if (x == 20) glds16_m0set<2048>(src[2] + (long)(R + 4) * 64 - 2048);                           \
+                    if (x == 28) glds16_m0set<3072>(src[3] + (long)(R + 4) * 64 - 3072);                           \
+                }                                                                                                  \
+            } else                                                                                                 \
+            if (ABL & ABL_REG) {                                                                                  \
+                if (x % DMA_EVERY == 1 && R + 2 < nR)                                                              \
+                    *reinterpret_cast<uint4*>(smem + ((R + 2) & 3) * REGION + dst[x / DMA_EVERY] + lane * 16) = stg[(S)][x / DMA_EVERY]; \
+                if (x % DMA_EVERY == 5 && R + 4 < nR)                                                              \
+                    stg[(S)][x / DMA_EVERY] = *reinterpret_cast<const uint4*>(src[x / DMA_EVERY] + ((ABL & ABL_SAMEK) ? 0L : (long)(R + 4) * 64)); \
+            } else                                                                                                 \
             if (ABL & ABL_STAGGER) { if (x % DMA_EVERY == wslot) issue1(R + 4, x / DMA_EVERY); }                   \
             else if (ABL & ABL_STAGGER2) { if (x % DMA_EVERY == wslot2) issue1(R + 4, x / DMA_EVERY); }             \
-            else if (!(ABL & ABL_NODMA) && x % DMA_EVERY == DMA_EVERY / 2) issue1(R + 4, x / DMA_EVERY);           \
+            else if (!(ABL & (ABL_NODMA | ABL_TAIL | ABL_ASYM)) && x % DMA_EVERY == DMA_EVERY / 2) issue1(R + 4, x / DMA_EVERY); \
             if (x % 2 == 1) __builtin_amdgcn_sched_barrier(0);                                                     \
         }                                                                                                          \
+        if ((ABL & (ABL_TAIL | ABL_ASYM)) && loader) { _Pragma("unroll") for (int j = 0; j < PPW; ++j) issue1(R + 4, j); } \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
-        if (!(ABL & (ABL_NODMA | ABL_NOWAIT))) {                                                                   \
+        if (loader && !(ABL & (ABL_NODMA | ABL_NOWAIT | ABL_REG))) {                                                                   \
             if (R + 4 < nR) wait_vmcnt<2 * PPW>(); else if (R + 3 < nR) wait_vmcnt<PPW>(); else wait_vmcnt<0>();    \
         }                                                                                                          \
         if (!(ABL & ABL_NOBAR)) __builtin_amdgcn_s_barrier();                                                      \
@@ -252,17 +310,16 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(href.data(), dref, href.size() * 4, hipMemcpyDeviceToHost));
 
     Variant vs[] = {
-        {"ring4 (4 waves 128x128)", launch<2, 0>, 4, true},
         {"ring8 (8 waves 128x64)", launch<4, 0>, 8, true},
-        {"ring16 (16 waves 64x64)", launch<4, 0, 4>, 16, true},
-        {"ring16 no-dma", launch<4, ABL_NODMA, 4>, 16, false},
-        {"ring16 no-read", launch<4, ABL_NOREAD, 4>, 16, false},
         {"ring8 no-read", launch<4, ABL_NOREAD>, 8, false},
         {"ring8 no-dma", launch<4, ABL_NODMA>, 8, false},
         {"ring8 no-read no-dma", launch<4, ABL_NOREAD | ABL_NODMA>, 8, false},
         {"ring8 no-read no-dma no-barrier", launch<4, ABL_NOREAD | ABL_NODMA | ABL_NOBAR>, 8, false},
-        {"ring8 staggered DMA slots", launch<4, ABL_STAGGER>, 8, true},
-        {"ring8 staggered DMA slots (partners adjacent)", launch<4, ABL_STAGGER2>, 8, true},
+        {"ring8 M0 written once per step", launch<4, ABL_M0ONCE>, 8, true},
+        {"ring8 buffer_load..lds", launch<4, ABL_BUF>, 8, true},
+        {"ring8 buffer_load..lds, same-tile same-k no-wait", launch<4, ABL_BUF | ABL_SAMETILE | ABL_SAMEK | ABL_NOWAIT>, 8, false},
+        {"ring8 DMA at the end of the step (every wave its 4)", launch<4, ABL_TAIL>, 8, true},
+        {"ring8 DMA at the end, waves 0-3 only (8 each)", launch<4, ABL_ASYM>, 8, true},
         {"ring8 no-wait (vmcnt never awaited)", launch<4, ABL_NOWAIT>, 8, false},
         {"ring8 same-k (every region from k 0)", launch<4, ABL_SAMEK>, 8, false},
         {"ring8 same-tile (all WGs tile 0,0)", launch<4, ABL_SAMETILE>, 8, false},

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().adcdiff_abi_version() == 1
+    assert _lib.load().adcdiff_abi_version() == 2
 
 
 def test_size_queries_and_argument_errors_without_gpu():
@@ -107,7 +107,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     gcc = shutil.which("gcc")
     if gcc is None:
         pytest.skip("gcc not available")
-    pairs = [("adcdiff_gn_out", _lib.GnOut), ("adcdiff_gemm_args", _lib.GemmArgs), ("adcdiff_ddpm_coef", _lib.DdpmCoef),
+    pairs = [("adcdiff_gn_out", _lib.GnOut), ("adcdiff_step_update", _lib.StepUpdate), ("adcdiff_gemm_args", _lib.GemmArgs), ("adcdiff_ddpm_coef", _lib.DdpmCoef),
              ("adcdiff_ddim_coef", _lib.DdimCoef), ("adcdiff_block_params", _lib.BlockParams), ("adcdiff_unet_params", _lib.UnetParams),
              ("adcdiff_block_grads", _lib.BlockGrads), ("adcdiff_unet_grads", _lib.UnetGrads), ("adcdiff_timing_record", _lib.TimingRecord),
              ("adcdiff_opt_tensor", _lib.OptTensor), ("adcdiff_adamw_args", _lib.AdamWArgs)]

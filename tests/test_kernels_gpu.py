@@ -143,6 +143,48 @@ def test_gemm_asymmetric_layout():
     assert np.array_equal(out, _bf16_round(W).T)
 
 
+@pytest.mark.parametrize("dtype,M,N,hint", [("bf16", 256, 256, 128), ("bf16", 512, 256, 256), ("bf16", 512, 256, 2561), ("fp32", 128, 128, 0),
+                                            ("bf16", 128, 128, 0)])
+def test_gemm_applies_the_schedule_update_like_the_stand_alone_kernels(dtype, M, N, hint):
+    """The sampler's reverse step inside the output GEMM's epilogue: the latent it writes equals, bit for bit, what
+    adcdiff_ddpm_step / adcdiff_ddim_step make of the same GEMM's stored result (injected noise and in-kernel Philox, in
+    place on x), and the operand-type copy and the SiLU(GroupNorm) output are formed from that latent."""
+    rng = np.random.default_rng(M + N)
+    K, gs = 192, 16
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    A = _t(rng.standard_normal((M, K)).astype(np.float32), td)
+    W = _t((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32), td)
+    bias = _t(rng.standard_normal(N).astype(np.float32))
+    gam = (1 + 0.2 * rng.standard_normal(N)).astype(np.float32)
+    bet = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    x = _t((rng.standard_normal((M, N)) * 4).astype(np.float32))
+    nz = _t(rng.standard_normal((M, N)).astype(np.float32))
+    live = M - 7
+    eps = ops._raw_gemm([A], W, bias=bias, m_valid=live, dtype=dtype, tile_hint=hint)
+    ddpm_c, ddim_c = (1.0101, 0.02, 0.9, 0.14), (0.9, 0.436, 0.5, 0.85, 0.1)
+    cases = [(1, ddpm_c, nz), (1, ddpm_c, None), (1, ddpm_c[:3] + (0.0,), None), (2, ddim_c, nz), (2, ddim_c, None), (2, ddim_c[:4] + (0.0,), None)]
+    for kind, c, noise in cases:
+        step = ops._raw_ddpm_step if kind == 1 else ops._raw_ddim_step
+        want = step(x, eps, c, noise=noise, seed=91, step=17, row_offset=1000)
+        xin = x.clone()
+        got, got_op, got_gn = ops._raw_gemm([A], W, bias=bias, m_valid=live, dtype=dtype, tile_hint=hint, out_op=True,
+                                            gn=[(_t(gam), _t(bet), gs)],
+                                            update=dict(kind=kind, c=c, x=xin, noise=noise, seed=91, step=17, row_offset=1000))
+        assert torch.equal(got[:live], want[:live]), (kind, c, noise is None)
+        assert torch.equal(got_op[:live], want[:live].to(td))
+        ref = _gn_silu_ref(want.cpu().numpy().astype(np.float64), gam, bet, gs)
+        err = np.abs(got_gn.float().cpu().numpy()[:live] - ref[:live]).max()
+        assert err < (2.0 ** -8 * np.abs(ref).max() + 1e-5 if dtype == "bf16" else 2e-5), err
+        assert torch.equal(xin, x)   # the latent is only read unless out_f32 aliases it
+    # in place: out_f32 = x
+    lib_args = dict(kind=1, c=ddpm_c, x=x, noise=None, seed=91, step=17, row_offset=1000)
+    want = ops._raw_ddpm_step(x, eps, ddpm_c, seed=91, step=17, row_offset=1000)
+    got = ops._raw_gemm([A], W, bias=bias, m_valid=live, dtype=dtype, tile_hint=hint, update=lib_args, out_f32=x)
+    assert got.data_ptr() == x.data_ptr() and torch.equal(x[:live], want[:live])
+    with pytest.raises(adcdiff.AdcdiffError):
+        ops._raw_gemm([A], W, bias=bias, dtype=dtype, act=1, update=lib_args)
+
+
 @pytest.mark.parametrize("C,G", [(128, 32), (256, 32), (512, 32), (1024, 32), (2048, 32), (4096, 32), (192, 32), (64, 32), (2048, 16)])
 def test_groupnorm_silu(C, G):
     rng = np.random.default_rng(C)
