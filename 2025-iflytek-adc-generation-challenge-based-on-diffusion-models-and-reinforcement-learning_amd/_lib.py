@@ -90,6 +90,8 @@ SIGNATURES = {
     "adcdiff_abi_version": (C.c_int, []),
     "adcdiff_last_error": (C.c_char_p, []),
     "adcdiff_gemm": (C.c_int, [C.POINTER(GemmArgs), c_fp]),
+    "adcdiff_gemm_tr": (C.c_int, [C.c_int, c_fp, C.c_longlong, c_fp, C.c_longlong, c_fp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_longlong, c_fp]),
     "adcdiff_groupnorm_silu": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_float, C.c_int, c_fp,
                                          C.c_int, c_fp, C.c_int, c_fp]),
     "adcdiff_philox_normal": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, c_fp]),

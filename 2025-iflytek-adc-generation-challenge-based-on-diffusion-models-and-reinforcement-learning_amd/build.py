@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadcdiff.so")
-SOURCES = [("gemm.hip", []), ("elementwise.hip", ["-ffp-contract=off"]), ("unet.hip", []), ("train.hip", [])]
+SOURCES = [("gemm.hip", []), ("gemm_tr.hip", []), ("elementwise.hip", ["-ffp-contract=off"]), ("unet.hip", []), ("train.hip", [])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

@@ -39,6 +39,44 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
+// ---------------------------------------------------------------- LDS-DMA staging helpers
+// LDS-DMA copy of 16 bytes per lane: the wave's 64 lanes fill 1 KiB starting at the wave-uniform `lds`.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// The same copy issued from inline asm: hipcc does not track it, so it inserts no vmcnt(0) in front of the next ds_read
+// (which it does for the builtin whenever the destination may alias) and a prefetch really stays in flight under the
+// MFMAs; the loops that use it count vmcnt by hand.  M0 carries the wave-uniform LDS byte address and is restored.
+__device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `tiles` (wave-uniform, 0..7) groups of P vector-memory operations are outstanding
+template <int P>
+__device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
+    switch (tiles) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<P>(); break;
+        case 2: wait_vmcnt<2 * P>(); break;
+        case 3: wait_vmcnt<3 * P>(); break;
+        case 4: wait_vmcnt<(4 * P <= 63 ? 4 * P : 63)>(); break;
+        case 5: wait_vmcnt<(5 * P <= 63 ? 5 * P : 63)>(); break;
+        case 6: wait_vmcnt<(6 * P <= 63 ? 6 * P : 63)>(); break;
+        default: wait_vmcnt<(7 * P <= 63 ? 7 * P : 63)>(); break;
+    }
+}
+
 // ---------------------------------------------------------------- Philox4x32-10 noise
 // counter = (col / 4, row, step, stream), key = (seed lo, seed hi); the four output words give the
 // four normals of columns 4q..4q+3 by two Box-Muller pairs (see oracle/philox.py for the definition).

@@ -119,6 +119,19 @@ def _raw_gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=Non
     return outs[0] if len(outs) == 1 else tuple(outs)
 
 
+def _raw_gemm_tr(a, b, ta, slices=1):
+    """adcdiff_gemm_tr: bf16 operands stored contraction-major.  b [K, N]; a [K, M] when ta else [M, K].
+    Returns float32 [M, N], or [slices, M, N] partial products when slices > 1."""
+    lib = _lib.load()
+    _need_gpu(a, b)
+    K, N = b.shape
+    M = a.shape[1] if ta else a.shape[0]
+    out = torch.empty((slices, M, N) if slices > 1 else (M, N), device=a.device, dtype=torch.float32)
+    check(lib.adcdiff_gemm_tr(int(bool(ta)), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), N, M, N, K, int(slices),
+                              M * N, _stream()))
+    return out
+
+
 def linear(x, weight, bias, act=0, dtype="fp32"):
     """nn.Linear on [B, K] float32 input (any B); returns [B, N] float32."""
     code = dtype_code(dtype)

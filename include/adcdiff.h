@@ -123,6 +123,17 @@ typedef struct adcdiff_gemm_args {
 } adcdiff_gemm_args;
 int adcdiff_gemm(const adcdiff_gemm_args* args, adcdiff_stream_t stream);
 
+/* bf16 GEMM with contraction-major operands, float32 output: C[M, N] = sum_k A(m, k) * B[k, N].
+ * B is [K, ldb] row-major (the contraction index is the ROW); A is [K, lda] row-major when ta != 0, else [M, lda] row-major.
+ * These are the two products of the backward pass of y = x W^T (diffusion_model.py:436 loss.backward() through the nn.Linear
+ * layers of :852-853, 867-870, 878) taken on the operands as the forward pass left them, with no transposed copies:
+ *   d(x) = d(y) W        ta = 0, A = d(y) [rows, out], B = W [out, in]
+ *   d(W) = d(y)^T x      ta = 1, A = d(y) [rows, out], B = x [rows, in]     (K = rows)
+ * M, N multiples of 128; K a multiple of 64 * slices.  slices > 1 cuts the contraction into equal parts computed by separate
+ * workgroups, part s writing C + s * c_slice (the caller sums the parts in order). */
+int adcdiff_gemm_tr(int ta, const void* A, long long lda, const void* B, long long ldb, float* C, long long ldc,
+                    int M, int N, int K, int slices, long long c_slice, adcdiff_stream_t stream);
+
 /* out = SiLU(GroupNorm(x)) for x [M, C] float32 with `groups` contiguous channel groups, biased variance,
  * eps inside the root (nn.GroupNorm + F.silu, diffusion_model.py:888-889, 896-897, 786-787).  out has
  * out_dtype; raw_out (optional, same dtype) receives x itself converted to that type: the

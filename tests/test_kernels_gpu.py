@@ -185,6 +185,42 @@ def test_gemm_applies_the_schedule_update_like_the_stand_alone_kernels(dtype, M,
         ops._raw_gemm([A], W, bias=bias, dtype=dtype, act=1, update=lib_args)
 
 
+@pytest.mark.parametrize("ta,M,N,K,slices", [(True, 128, 128, 64, 1), (True, 256, 384, 512, 1), (True, 128, 256, 1024, 4), (False, 128, 128, 64, 1),
+                                               (False, 384, 256, 448, 1), (False, 256, 128, 768, 3)])
+def test_contraction_major_gemm_equals_the_nt_kernel_on_transposed_copies(ta, M, N, K, slices):
+    """adcdiff_gemm_tr reads operands as the forward pass stored them (contraction index = row) through transposed LDS
+    reads; the same product through the NT kernel on explicitly transposed copies gives the same float32 bits (same MFMA,
+    same k order), and both match float64.  Asymmetric operands and strided views catch a swapped or permuted layout."""
+    rng = np.random.default_rng(M + N + K)
+    bf = torch.bfloat16
+    lda_pad, ldb_pad = 8, 16
+    Bfull = _t(rng.standard_normal((K, N + ldb_pad)).astype(np.float32), bf)
+    Bm = Bfull[:, :N]                                           # [K, N], row stride N + 16
+    if ta:
+        Afull = _t(rng.standard_normal((K, M + lda_pad)).astype(np.float32), bf)
+        A = Afull[:, :M]                                        # [K, M]
+        A_nt = A.t().contiguous()
+    else:
+        Afull = _t(rng.standard_normal((M, K + lda_pad)).astype(np.float32), bf)
+        A = Afull[:, :K]                                        # [M, K]
+        A_nt = A.contiguous()
+    got = ops._raw_gemm_tr(A, Bm, ta, slices=slices)
+    ref64 = A_nt.double().cpu().numpy() @ Bm.double().cpu().numpy()
+    if slices > 1:
+        assert got.shape == (slices, M, N)
+        ks = K // slices
+        for s_ in range(slices):
+            part = ops._raw_gemm([A_nt[:, s_ * ks:(s_ + 1) * ks].contiguous()], Bm.t()[:, s_ * ks:(s_ + 1) * ks].contiguous(), dtype="bf16", tile_hint=128)
+            assert torch.equal(got[s_], part), s_
+        got = got.sum(0)
+    else:
+        nt = ops._raw_gemm([A_nt], Bm.t().contiguous(), dtype="bf16", tile_hint=128)
+        assert torch.equal(got, nt)
+    assert rel_err(got.cpu().numpy(), ref64) < 1e-5
+    with pytest.raises(adcdiff.AdcdiffError):
+        ops._raw_gemm_tr(A, Bm, ta, slices=5)
+
+
 @pytest.mark.parametrize("C,G", [(128, 32), (256, 32), (512, 32), (1024, 32), (2048, 32), (4096, 32), (192, 32), (64, 32), (2048, 16)])
 def test_groupnorm_silu(C, G):
     rng = np.random.default_rng(C)
