@@ -281,7 +281,9 @@ static int gemm_simple(int dt, const void* A, int lda, const void* W, int ldw, i
 }
 
 // dst[e] = sum over s of part[s * stride + e], slices in index order (n % 4 == 0, 16-byte aligned)
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int slices, long stride, long n4, float* __restrict__ dst) {
+// (the partials are [rows, cols] contiguous; dst rows are ldd floats apart)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int slices, long stride, long n4, float* __restrict__ dst,
+                                                           int cols, long ldd) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     if (q >= n4) return;
     f32x4 acc = *reinterpret_cast<const f32x4*>(part + q * 4);
@@ -289,7 +291,8 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
         const f32x4 v = *reinterpret_cast<const f32x4*>(part + (long)s * stride + q * 4);
         acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
     }
-    *reinterpret_cast<f32x4*>(dst + q * 4) = acc;
+    const long e = q * 4, r = e / cols, c = e - r * cols;
+    *reinterpret_cast<f32x4*>(dst + r * ldd + c) = acc;
 }
 
 // K slices for a weight-gradient GEMM out[M, N] = A[M, K] W[N, K]^T whose K is the batch: enough that slices x tiles fill
@@ -319,8 +322,35 @@ static int gemm_dw(int dt, const void* A, const void* W, int M, int N, int K, fl
     TRY(gemm_dispatch(g, st));
     const long n4 = (long)M * N / 4;
     TimingScope ts(ADCDIFF_KIND_OTHER, M, N, 0, 0.0, (double)M * N * 4.0 * (slices + 1), st);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, slices, (long)M * N, n4, out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, slices, (long)M * N, n4, out, N, (long)N);
     return check_launch("sum_partials");
+}
+
+// d(weight)[M, N] (rows ldo apart) = dY[K, M]^T X[K, N] on the operands as the forward pass stored them (K = batch rows), the
+// contraction cut into slices when M x N alone leaves most CUs idle; partials are summed in slice order.
+static int gemm_dw_direct(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, float* out, long ldo, int n_whole, Bump& ws,
+                          bool dry, hipStream_t st) {
+    // the slicing of the transposing path (which takes a concatenated input in one product of n_whole columns): same bits
+    const int slices = dw_slices(M, n_whole, K);
+    if (slices == 1) {
+        if (dry) return ADCDIFF_OK;
+        return gemm_tr(true, dY, ldy, X, ldx, out, ldo, M, N, K, 1, 0, st);
+    }
+    const size_t keep = ws.off;
+    float* part = (float*)ws.take((size_t)slices * M * N * 4);
+    ws.off = keep;
+    if (dry) return ADCDIFF_OK;
+    TRY(gemm_tr(true, dY, ldy, X, ldx, part, N, M, N, K, slices, (long)M * N, st));
+    const long n4 = (long)M * N / 4;
+    TimingScope ts(ADCDIFF_KIND_OTHER, M, N, 0, 0.0, (double)M * N * 4.0 * (slices + 1), st);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, slices, (long)M * N, n4, out, N, ldo);
+    return check_launch("sum_partials");
+}
+
+// measurement aid: ADCDIFF_TRAIN_TRANSPOSE=1 keeps the backward pass on the NT kernel with transposed copies
+static bool direct_enabled() {
+    const char* e = getenv("ADCDIFF_TRAIN_TRANSPOSE");   // read per call: a test switches it between two backward passes
+    return !(e && atoi(e) != 0);
 }
 
 static int copy_f32(const float* src, float* dst, long n, int accumulate, hipStream_t st) {
@@ -426,7 +456,19 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
     if (!dry && hipMemsetAsync(d_tb, 0, (size_t)Tp * SN * 4, st) != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "unet_backward: memset failed");
 
     // ---- output head: eps = out_layer(a_out), a_out = SiLU(output_norm(o9)) (diffusion_model.py:786-788)
-    {
+    // bf16 with whole 64-row contraction tiles: the backward GEMMs read d(y), the saved activations and the packed weights as
+    // they are (gemm_tr); otherwise the NT kernel on transposed copies
+    const bool direct = dt == ADCDIFF_BF16 && B % 64 == 0 && direct_enabled();
+    if (direct) {
+        void* dE_rm = ws.take((size_t)Bp * O * e);
+        RUN(cast_transpose<float>(d_eps, lde, B, Bp, O, dt, dE_rm, O, nullptr, 0, gr->out_b, st));
+        TRY(gemm_dw_direct(dE_rm, O, tp.a_out, H, O, H, B, gr->out_w, H, H, ws, dry, st));
+        float* d_a = (float*)ws.take((size_t)Bp * H * 4);
+        RUN(gemm_tr(false, dE_rm, O, n->w_out, H, d_a, H, Bp, H, O, 1, 0, st));
+        TRY(gn_silu_bwd(tp.blk[9].o, n->blk[9].cout, d_a, H, B, H, num_groups(H), p.out_norm_w, p.out_norm_b, 0.0f, 0, 0, 0, nullptr, 0, dO[9],
+                        n->blk[9].cout, 0, gr->out_norm_w, gr->out_norm_b, ws, dry, st));
+        dO_written[9] = true;
+    } else {
         void* dE_rm = ws.take((size_t)Bp * O * e);
         void* dE_t = ws.take((size_t)O * Bp * e);
         RUN(cast_transpose<float>(d_eps, lde, B, Bp, O, dt, dE_rm, O, dE_t, Bp, gr->out_b, st));
@@ -450,54 +492,97 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         const adcdiff_block_params& q = p.blocks[i];
         const adcdiff_block_grads& g = gr->blocks[i];
         const int cin = b.cin, cout = b.cout;
-        // (1) dO in the operand type, row-major and transposed; its column sums are d(linear2.bias) (= d(residual_proj.bias))
-        void* dO_rm = ws.take((size_t)Bp * cout * e);
-        void* dO_t = ws.take((size_t)cout * Bp * e);
-        RUN(cast_transpose<float>(dO[i], cout, B, Bp, cout, dt, dO_rm, cout, dO_t, Bp, g.linear2_b, st));
-        if (b.has_res) RUN(copy_f32(g.linear2_b, g.residual_b, cout, 0, st));
-        // (2) d(linear2.weight) = dO^T a2
-        void* xT = ws.take((size_t)(cin > cout ? cin : cout) * Bp * e);
-        RUN(transpose_op(bt.a2, cout, B, Bp, cout, dt, xT, st));
-        TRY(gemm_dw(dt, dO_t, xT, cout, cout, Bp, g.linear2_w, ws, dry, st));
-        // (3) residual_proj: d(weight) = dO^T x, d(x) = dO Wres
         float* d_raw = nullptr;
-        void* wT = ws.take((size_t)(cin > cout ? cin : cout) * cout * e);
-        if (b.has_res) {
-            int row0 = 0;
-            for (int k = 0; k < b.nparts; ++k) {
-                RUN(transpose_op(bt.in_raw[k], b.part_c[k], B, Bp, b.part_c[k], dt, (char*)xT + (size_t)row0 * Bp * e, st));
-                row0 += b.part_c[k];
+        float* d_a1 = nullptr;
+        long ld_raw = cin;
+        if (direct) {
+            // (1) dO in bf16; its column sums are d(linear2.bias) (= d(residual_proj.bias))
+            void* dY = ws.take((size_t)Bp * cout * e);
+            RUN(cast_transpose<float>(dO[i], cout, B, Bp, cout, dt, dY, cout, nullptr, 0, g.linear2_b, st));
+            if (b.has_res) RUN(copy_f32(g.linear2_b, g.residual_b, cout, 0, st));
+            // (2) d(linear2.weight) = dO^T a2; (3) d(residual_proj.weight) = dO^T x, part by part
+            TRY(gemm_dw_direct(dY, cout, bt.a2, cout, cout, cout, B, g.linear2_w, cout, cout, ws, dry, st));
+            if (b.has_res) {
+                int col0 = 0;
+                for (int k = 0; k < b.nparts; ++k) {
+                    TRY(gemm_dw_direct(dY, cout, bt.in_raw[k], b.part_c[k], cout, b.part_c[k], B, g.residual_w + col0, cin, cin, ws, dry, st));
+                    col0 += b.part_c[k];
+                }
             }
-            TRY(gemm_dw(dt, dO_t, xT, cout, cin, Bp, g.residual_w, ws, dry, st));
-            RUN(cast_transpose<float>(q.residual_w, cin, cout, cout, cin, dt, nullptr, 0, wT, cout, nullptr, st));
-            d_raw = (float*)ws.take((size_t)Bp * cin * 4);
-            RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cin, cout, d_raw, cin, st));
-        }
-        // (4) d(a2) = dO W2; (5) through dropout, SiLU and norm2 to d(h1)
-        RUN(cast_transpose<float>(q.linear2_w, cout, cout, cout, cout, dt, nullptr, 0, wT, cout, nullptr, st));
-        float* d_a2 = (float*)ws.take((size_t)Bp * cout * 4);
-        RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cout, cout, d_a2, cout, st));
-        float* d_h1 = (float*)ws.take((size_t)Bp * cout * 4);
-        TRY(gn_silu_bwd(bt.h1, cout, d_a2, cout, B, cout, b.g2, q.norm2_w, q.norm2_b, tp.drop_p, tp.drop_seed, (uint32_t)i, 0, nullptr, 0, d_h1,
-                        cout, 0, g.norm2_w, g.norm2_b, ws, dry, st));
-        // (6) d(h1): column sums are d(linear1.bias) = d(time_proj.bias); (7) rows go to the timestep table
-        RUN(cast_transpose<float>(d_h1, cout, B, Bp, cout, dt, dO_rm, cout, dO_t, Bp, g.linear1_b, st));
-        RUN(copy_f32(g.linear1_b, g.time_proj_b, cout, 0, st));
-        {
-            const long total = (long)B * cout;
-            if (!dry) {
-                TimingScope ts(ADCDIFF_KIND_OTHER, B, cout, 0, 0.0, (double)total * 12.0, st);
-                hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_h1, (long)cout, tp.t_rows, B,
-                                   cout, d_tb, (long)SN, b.tb_off, n->T);
-                TRY(check_launch("scatter_add_rows"));
+            // (4) [d(a2) | d(x) through residual_proj] = dO [W2 | Wres] in one product on the packed weight
+            const int n2 = b.has_res ? cout + cin : cout;
+            float* d_both = (float*)ws.take((size_t)Bp * n2 * 4);
+            RUN(gemm_tr(false, dY, cout, b.w2cat, b.ldw2, d_both, n2, Bp, n2, cout, 1, 0, st));
+            if (b.has_res) { d_raw = d_both + cout; ld_raw = n2; }
+            // (5) through dropout, SiLU and norm2 to d(h1)
+            float* d_h1 = (float*)ws.take((size_t)Bp * cout * 4);
+            TRY(gn_silu_bwd(bt.h1, cout, d_both, n2, B, cout, b.g2, q.norm2_w, q.norm2_b, tp.drop_p, tp.drop_seed, (uint32_t)i, 0, nullptr, 0, d_h1,
+                            cout, 0, g.norm2_w, g.norm2_b, ws, dry, st));
+            // (6) d(h1) in bf16: column sums are d(linear1.bias) = d(time_proj.bias); (7) rows go to the timestep table
+            RUN(cast_transpose<float>(d_h1, cout, B, Bp, cout, dt, dY, cout, nullptr, 0, g.linear1_b, st));
+            RUN(copy_f32(g.linear1_b, g.time_proj_b, cout, 0, st));
+            {
+                const long total = (long)B * cout;
+                if (!dry) {
+                    TimingScope ts(ADCDIFF_KIND_OTHER, B, cout, 0, 0.0, (double)total * 12.0, st);
+                    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_h1, (long)cout, tp.t_rows, B,
+                                       cout, d_tb, (long)SN, b.tb_off, n->T);
+                    TRY(check_launch("scatter_add_rows"));
+                }
             }
+            // (8) d(linear1.weight) = d_h1^T a1; (9) d(a1) = d_h1 W1 (the first cin columns of the packed [W1 | Wtp])
+            TRY(gemm_dw_direct(dY, cout, bt.a1, cin, cout, cin, B, g.linear1_w, cin, cin, ws, dry, st));
+            d_a1 = (float*)ws.take((size_t)Bp * cin * 4);
+            RUN(gemm_tr(false, dY, cout, b.w1cat, b.ldw1, d_a1, cin, Bp, cin, cout, 1, 0, st));
+        } else {
+            // (1) dO in the operand type, row-major and transposed; its column sums are d(linear2.bias) (= d(residual_proj.bias))
+            void* dO_rm = ws.take((size_t)Bp * cout * e);
+            void* dO_t = ws.take((size_t)cout * Bp * e);
+            RUN(cast_transpose<float>(dO[i], cout, B, Bp, cout, dt, dO_rm, cout, dO_t, Bp, g.linear2_b, st));
+            if (b.has_res) RUN(copy_f32(g.linear2_b, g.residual_b, cout, 0, st));
+            // (2) d(linear2.weight) = dO^T a2
+            void* xT = ws.take((size_t)(cin > cout ? cin : cout) * Bp * e);
+            RUN(transpose_op(bt.a2, cout, B, Bp, cout, dt, xT, st));
+            TRY(gemm_dw(dt, dO_t, xT, cout, cout, Bp, g.linear2_w, ws, dry, st));
+            // (3) residual_proj: d(weight) = dO^T x, d(x) = dO Wres
+            void* wT = ws.take((size_t)(cin > cout ? cin : cout) * cout * e);
+            if (b.has_res) {
+                int row0 = 0;
+                for (int k = 0; k < b.nparts; ++k) {
+                    RUN(transpose_op(bt.in_raw[k], b.part_c[k], B, Bp, b.part_c[k], dt, (char*)xT + (size_t)row0 * Bp * e, st));
+                    row0 += b.part_c[k];
+                }
+                TRY(gemm_dw(dt, dO_t, xT, cout, cin, Bp, g.residual_w, ws, dry, st));
+                RUN(cast_transpose<float>(q.residual_w, cin, cout, cout, cin, dt, nullptr, 0, wT, cout, nullptr, st));
+                d_raw = (float*)ws.take((size_t)Bp * cin * 4);
+                RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cin, cout, d_raw, cin, st));
+            }
+            // (4) d(a2) = dO W2; (5) through dropout, SiLU and norm2 to d(h1)
+            RUN(cast_transpose<float>(q.linear2_w, cout, cout, cout, cout, dt, nullptr, 0, wT, cout, nullptr, st));
+            float* d_a2 = (float*)ws.take((size_t)Bp * cout * 4);
+            RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cout, cout, d_a2, cout, st));
+            float* d_h1 = (float*)ws.take((size_t)Bp * cout * 4);
+            TRY(gn_silu_bwd(bt.h1, cout, d_a2, cout, B, cout, b.g2, q.norm2_w, q.norm2_b, tp.drop_p, tp.drop_seed, (uint32_t)i, 0, nullptr, 0, d_h1,
+                            cout, 0, g.norm2_w, g.norm2_b, ws, dry, st));
+            // (6) d(h1): column sums are d(linear1.bias) = d(time_proj.bias); (7) rows go to the timestep table
+            RUN(cast_transpose<float>(d_h1, cout, B, Bp, cout, dt, dO_rm, cout, dO_t, Bp, g.linear1_b, st));
+            RUN(copy_f32(g.linear1_b, g.time_proj_b, cout, 0, st));
+            {
+                const long total = (long)B * cout;
+                if (!dry) {
+                    TimingScope ts(ADCDIFF_KIND_OTHER, B, cout, 0, 0.0, (double)total * 12.0, st);
+                    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_h1, (long)cout, tp.t_rows, B,
+                                       cout, d_tb, (long)SN, b.tb_off, n->T);
+                    TRY(check_launch("scatter_add_rows"));
+                }
+            }
+            // (8) d(linear1.weight) = d_h1^T a1; (9) d(a1) = d_h1 W1
+            RUN(transpose_op(bt.a1, cin, B, Bp, cin, dt, xT, st));
+            TRY(gemm_dw(dt, dO_t, xT, cout, cin, Bp, g.linear1_w, ws, dry, st));
+            RUN(cast_transpose<float>(q.linear1_w, cin, cout, cout, cin, dt, nullptr, 0, wT, cout, nullptr, st));
+            d_a1 = (float*)ws.take((size_t)Bp * cin * 4);
+            RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cin, cout, d_a1, cin, st));
         }
-        // (8) d(linear1.weight) = d_h1^T a1; (9) d(a1) = d_h1 W1
-        RUN(transpose_op(bt.a1, cin, B, Bp, cin, dt, xT, st));
-        TRY(gemm_dw(dt, dO_t, xT, cout, cin, Bp, g.linear1_w, ws, dry, st));
-        RUN(cast_transpose<float>(q.linear1_w, cin, cout, cout, cin, dt, nullptr, 0, wT, cout, nullptr, st));
-        float* d_a1 = (float*)ws.take((size_t)Bp * cin * 4);
-        RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cin, cout, d_a1, cin, st));
         // (10) through SiLU and norm1 of each input part; the result plus the residual-path gradient is the gradient of the
         // tensor that part came from (previous block, or the encoder output of a skip connection)
         float* scratch = (float*)ws.take((size_t)Bp * b.part_c[0] * 4);
@@ -508,7 +593,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             const int lddst = b.part_c[k];
             const int acc = src >= 0 && dO_written[src] ? 1 : 0;
             const float* add = b.has_res ? d_raw + col : dO[i];     // Identity residual passes dO straight through
-            const long ldadd = b.has_res ? cin : cout;
+            const long ldadd = b.has_res ? ld_raw : cout;
             TRY(gn_silu_bwd(bt.in_f32[k], bt.in_ld[k], d_a1 + col, cin, B, b.part_c[k], b.part_c[k] / b.gs1, q.norm1_w + col, q.norm1_b + col, 0.0f,
                             0, 0, 0, add, ldadd, dst, lddst, acc, g.norm1_w + col, g.norm1_b + col, ws, dry, st));
             if (src >= 0) dO_written[src] = true;

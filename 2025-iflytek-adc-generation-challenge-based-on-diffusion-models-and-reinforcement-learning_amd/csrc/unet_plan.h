@@ -8,6 +8,9 @@
 namespace adcdiff {
 
 int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream);
+// gemm_tr.hip: bf16 product on contraction-major operands (see adcdiff_gemm_tr)
+int gemm_tr(bool ta, const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, int slices, long c_slice,
+            hipStream_t stream);
 int groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const float* gamma, const float* beta, float eps,
                    int out_dtype, void* out, int ldo, void* raw_out, int ldraw, hipStream_t stream, float drop_p = 0.0f,
                    uint64_t drop_seed = 0, uint32_t drop_layer = 0);
