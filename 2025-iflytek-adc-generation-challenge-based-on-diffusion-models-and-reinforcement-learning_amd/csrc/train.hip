@@ -604,16 +604,43 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
     //      te_pre = sinusoid W1^T + b1 (all float32, M = Tp rows of which only the drawn timesteps carry gradient)
     ws.off = mark;
     {
-        float* dTB_t = (float*)ws.take((size_t)SN * Tp * 4);
-        RUN(cast_transpose<float>(d_tb, SN, Tp, Tp, SN, ADCDIFF_F32, nullptr, 0, dTB_t, Tp, nullptr, st));
-        float* sT = (float*)ws.take((size_t)H * Tp * 4);
-        RUN(cast_transpose<float>(n->s_table, H, Tp, Tp, H, ADCDIFF_F32, nullptr, 0, sT, Tp, nullptr, st));
-        for (int i = 0; i < 10; ++i)
-            RUN(gemm_simple(ADCDIFF_F32, dTB_t + (size_t)n->blk[i].tb_off * Tp, Tp, sT, Tp, n->blk[i].cout, 0, H, Tp, gr->blocks[i].time_proj_w, H, st));
-        float* wtpT = (float*)ws.take((size_t)H * SN * 4);
-        RUN(cast_transpose<float>(n->wtp_all, H, SN, SN, H, ADCDIFF_F32, nullptr, 0, wtpT, SN, nullptr, st));
-        float* d_s = (float*)ws.take((size_t)Tp * H * 4);
-        RUN(gemm_simple(ADCDIFF_F32, d_tb, SN, wtpT, SN, Tp, 0, H, SN, d_s, H, st));
+        float* d_s = nullptr;
+        if (direct) {
+            // the two large products of the branch (contraction over the Tp timesteps and over all sumN time_proj outputs) on bf16
+            // copies of d_tb, s_table and the stacked time_proj weights, read as stored
+            void* dtb_op = ws.take((size_t)Tp * SN * e);
+            RUN(cast_transpose<float>(d_tb, SN, Tp, Tp, SN, dt, dtb_op, SN, nullptr, 0, nullptr, st));
+            void* s_op = ws.take((size_t)Tp * H * e);
+            RUN(cast_transpose<float>(n->s_table, H, Tp, Tp, H, dt, s_op, H, nullptr, 0, nullptr, st));
+            for (int i = 0; i < 10; ++i)
+                TRY(gemm_dw_direct((const char*)dtb_op + (size_t)n->blk[i].tb_off * e, SN, s_op, H, n->blk[i].cout, H, Tp, gr->blocks[i].time_proj_w, H,
+                                   H, ws, dry, st));
+            void* wtp_op = ws.take((size_t)SN * H * e);
+            RUN(cast_pack(n->wtp_all, H, dt, wtp_op, H, 0, SN, H, st));
+            d_s = (float*)ws.take((size_t)Tp * H * 4);
+            int slices = 1;
+            for (int c = 16; c > 1; --c)
+                if (SN % (64 * c) == 0) { slices = c; break; }
+            float* part = slices > 1 ? (float*)ws.take((size_t)slices * Tp * H * 4) : d_s;
+            RUN(gemm_tr(false, dtb_op, SN, wtp_op, H, part, H, Tp, H, SN, slices, (long)Tp * H, st));
+            if (slices > 1 && !dry) {
+                const long n4 = (long)Tp * H / 4;
+                TimingScope ts(ADCDIFF_KIND_OTHER, Tp, H, 0, 0.0, (double)Tp * H * 4.0 * (slices + 1), st);
+                hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, slices, (long)Tp * H, n4, d_s, H, (long)H);
+                TRY(check_launch("sum_partials"));
+            }
+        } else {
+            float* dTB_t = (float*)ws.take((size_t)SN * Tp * 4);
+            RUN(cast_transpose<float>(d_tb, SN, Tp, Tp, SN, ADCDIFF_F32, nullptr, 0, dTB_t, Tp, nullptr, st));
+            float* sT = (float*)ws.take((size_t)H * Tp * 4);
+            RUN(cast_transpose<float>(n->s_table, H, Tp, Tp, H, ADCDIFF_F32, nullptr, 0, sT, Tp, nullptr, st));
+            for (int i = 0; i < 10; ++i)
+                RUN(gemm_simple(ADCDIFF_F32, dTB_t + (size_t)n->blk[i].tb_off * Tp, Tp, sT, Tp, n->blk[i].cout, 0, H, Tp, gr->blocks[i].time_proj_w, H, st));
+            float* wtpT = (float*)ws.take((size_t)H * SN * 4);
+            RUN(cast_transpose<float>(n->wtp_all, H, SN, SN, H, ADCDIFF_F32, nullptr, 0, wtpT, SN, nullptr, st));
+            d_s = (float*)ws.take((size_t)Tp * H * 4);
+            RUN(gemm_simple(ADCDIFF_F32, d_tb, SN, wtpT, SN, Tp, 0, H, SN, d_s, H, st));
+        }
         float* d_te = (float*)ws.take((size_t)Tp * H * 4);
         if (!dry) {
             TimingScope ts(ADCDIFF_KIND_OTHER, Tp, H, 0, 0.0, (double)Tp * H * 12.0, st);

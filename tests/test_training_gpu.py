@@ -183,8 +183,12 @@ def test_backward_without_transposed_copies_gives_the_same_gradients(dims, B, mo
         if k.endswith(("linear1.weight", "linear2.weight", "residual_proj.weight", "output_layer.weight")) and not k.startswith("time_embed"):
             assert torch.equal(direct[k], copies[k]), k
             exact += 1
-        else:   # bias, GroupNorm and time-branch gradients are accumulated with atomics: equal to summation order
-            assert float((direct[k] - copies[k]).abs().max()) <= 1e-5 * max(float(copies[k].abs().max()), 1e-6), k
+        elif "time" in k and k.endswith("weight"):
+            # the time branch's large products run on bf16 copies of the table gradient in the direct path, float32 in the other
+            assert float((direct[k] - copies[k]).abs().max()) <= 2e-2 * max(float(copies[k].abs().max()), 1e-6), k
+        else:   # bias and GroupNorm gradients are accumulated with atomics: equal to summation order
+            tol = 2e-2 if "time_embed" in k else 1e-5
+            assert float((direct[k] - copies[k]).abs().max()) <= tol * max(float(copies[k].abs().max()), 1e-6), k
     assert exact >= 25
 
 
