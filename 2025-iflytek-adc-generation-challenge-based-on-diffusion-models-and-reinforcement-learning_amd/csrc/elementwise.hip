@@ -5,7 +5,7 @@
 #include <cmath>
 #include <mutex>
 
-#include "common.h"
+#include "unet_plan.h"
 
 #define TRY_RC(expr) do { int rc_ = (expr); if (rc_ != ADCDIFF_OK) return rc_; } while (0)
 
@@ -328,6 +328,42 @@ int cast_pack(const float* src, int lds_, int dtype, void* dst, int ldd, int col
         hipLaunchKernelGGL((cast_pack_kernel<float>), grid, dim3(256), 0, stream, src, lds_, reinterpret_cast<float*>(dst), ldd, col0,
                            rows, cols);
     return check_launch("cast_pack");
+}
+
+// every weight cast and bias sum of a pack in one launch: a workgroup takes one PACK_CHUNK-element chunk of one entry
+__global__ __launch_bounds__(256) void pack_items_kernel(const PackItem* __restrict__ items, int n_items) {
+    int lo = 0, hi = n_items - 1;
+    const long long chunk = blockIdx.x;
+    while (lo < hi) {   // last entry whose chunk_start <= chunk (workgroup-uniform)
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].chunk_start <= chunk) lo = mid; else hi = mid - 1;
+    }
+    const PackItem it = items[lo];
+#pragma unroll
+    for (int h = 0; h < PACK_CHUNK / 1024; ++h) {
+        const long long e = (chunk - it.chunk_start) * PACK_CHUNK + h * 1024 + threadIdx.x * 4;
+        if (e >= it.numel) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(it.src + e);
+        if (it.add) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(it.add + e);
+            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+        }
+        const long long r = e / it.cols;
+        const long long o = r * it.ldd + it.col0 + (e - r * it.cols);
+        if (it.dtype == ADCDIFF_BF16) {
+            bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(it.dst) + o) = b;
+        } else {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(it.dst) + o) = v;
+        }
+    }
+}
+
+int pack_items(const PackItem* items_dev, int n_items, long long total_chunks, hipStream_t stream) {
+    if (n_items <= 0 || total_chunks <= 0) return ADCDIFF_OK;
+    TimingScope ts(ADCDIFF_KIND_OTHER, n_items, 0, 0, 0.0, (double)total_chunks * PACK_CHUNK * 6.0, stream);
+    hipLaunchKernelGGL(pack_items_kernel, dim3((unsigned)total_chunks), dim3(256), 0, stream, items_dev, n_items);
+    return check_launch("pack_items");
 }
 
 int add_vec(const float* a, const float* b, float* out, int n, hipStream_t stream) {

@@ -66,6 +66,7 @@ static void carve_arena(adcdiff_unet* n, void* arena, size_t cap) {
     n->wtp_all = (float*)a.take((size_t)n->sumN * n->H * 4);
     n->btp_all = (float*)a.take((size_t)n->sumN * 4);
     n->tb_table = (float*)a.take((size_t)n->Tp * n->sumN * 4);
+    n->pack_table = (PackItem*)a.take(PACK_MAX_ITEMS * sizeof(PackItem));
     n->arena_used = a.off;
 }
 
@@ -110,7 +111,42 @@ extern "C" int adcdiff_unet_create(const adcdiff_unet_params* p, int dtype, void
             return fail(ADCDIFF_E_BADARG, "unet_create: block %d: residual_proj presence does not match its dimensions", i);
         }
     }
+    // the packing entries: every weight cast into the concatenated operand layouts, every bias sum, the stacked time_proj copies
+    {
+        PackItem items[PACK_MAX_ITEMS];
+        int k = 0;
+        long long chunks = 0;
+        auto add_item = [&](const float* src, const float* add, void* dst, int rows, int cols, int ldd, int col0, int dt) {
+            PackItem& it = items[k++];
+            it.src = src; it.add = add; it.dst = dst; it.cols = cols; it.ldd = ldd; it.col0 = col0; it.dtype = dt;
+            it.numel = (long long)rows * cols; it.chunk_start = chunks;
+            chunks += (it.numel + PACK_CHUNK - 1) / PACK_CHUNK;
+        };
+        const int H = n->H;
+        for (int i = 0; i < 10; ++i) {
+            const BlockPlan& b = n->blk[i];
+            const adcdiff_block_params& q = p->blocks[i];
+            add_item(q.linear1_w, nullptr, b.w1cat, b.cout, b.cin, b.ldw1, 0, dtype);
+            add_item(q.time_proj_w, nullptr, b.w1cat, b.cout, H, b.ldw1, b.cin, dtype);
+            add_item(q.linear2_w, nullptr, b.w2cat, b.cout, b.cout, b.ldw2, 0, dtype);
+            if (b.has_res) add_item(q.residual_w, nullptr, b.w2cat, b.cout, b.cin, b.ldw2, b.cout, dtype);
+            add_item(q.linear1_b, nullptr, b.bias1, 1, b.cout, b.cout, 0, ADCDIFF_F32);
+            add_item(q.linear1_b, q.time_proj_b, b.bias1_cond, 1, b.cout, b.cout, 0, ADCDIFF_F32);
+            add_item(q.linear2_b, b.has_res ? q.residual_b : nullptr, b.bias2, 1, b.cout, b.cout, 0, ADCDIFF_F32);
+            add_item(q.time_proj_w, nullptr, n->wtp_all + (size_t)b.tb_off * H, b.cout, H, H, 0, ADCDIFF_F32);
+            add_item(q.time_proj_b, nullptr, n->btp_all + b.tb_off, 1, b.cout, b.cout, 0, ADCDIFF_F32);
+        }
+        add_item(p->out_w, nullptr, n->w_out, n->O, H, H, 0, dtype);
+        add_item(p->cond0_w, nullptr, n->w_c0, H, n->D, n->D, 0, dtype);
+        add_item(p->cond2_w, nullptr, n->w_c2, H, H, H, 0, dtype);
+        n->n_pack = k; n->pack_chunks = chunks;
+        if (hipMemcpy(n->pack_table, items, (size_t)k * sizeof(PackItem), hipMemcpyHostToDevice) != hipSuccess) {
+            delete n;
+            return fail(ADCDIFF_E_LAUNCH, "unet_create: copying the packing table into the arena failed (is the arena device memory?)");
+        }
+    }
     n->packed = false;
+    n->sin_built = false;
     *out = n;
     return ADCDIFF_OK;
 }
@@ -130,25 +166,11 @@ extern "C" int adcdiff_unet_pack(adcdiff_unet* n, void* workspace, size_t worksp
     hipStream_t st = as_stream(stream_);
     const adcdiff_unet_params& p = n->prm;
     const int H = n->H;
-    for (int i = 0; i < 10; ++i) {
-        const BlockPlan& b = n->blk[i];
-        const adcdiff_block_params& q = p.blocks[i];
-        TRY(cast_pack(q.linear1_w, b.cin, n->dtype, b.w1cat, b.ldw1, 0, b.cout, b.cin, st));
-        TRY(cast_pack(q.time_proj_w, H, n->dtype, b.w1cat, b.ldw1, b.cin, b.cout, H, st));
-        TRY(cast_pack(q.linear2_w, b.cout, n->dtype, b.w2cat, b.ldw2, 0, b.cout, b.cout, st));
-        if (b.has_res) TRY(cast_pack(q.residual_w, b.cin, n->dtype, b.w2cat, b.ldw2, b.cout, b.cout, b.cin, st));
-        TRY(add_vec(q.linear1_b, nullptr, b.bias1, b.cout, st));
-        TRY(add_vec(q.linear1_b, q.time_proj_b, b.bias1_cond, b.cout, st));
-        TRY(add_vec(q.linear2_b, b.has_res ? q.residual_b : nullptr, b.bias2, b.cout, st));
-        TRY(cast_pack(q.time_proj_w, H, ADCDIFF_F32, n->wtp_all + (size_t)b.tb_off * H, H, 0, b.cout, H, st));
-        TRY(add_vec(q.time_proj_b, nullptr, n->btp_all + b.tb_off, b.cout, st));
-    }
-    TRY(cast_pack(p.out_w, H, n->dtype, n->w_out, H, 0, n->O, H, st));
-    TRY(cast_pack(p.cond0_w, n->D, n->dtype, n->w_c0, n->D, 0, H, n->D, st));
-    TRY(cast_pack(p.cond2_w, H, n->dtype, n->w_c2, H, 0, H, H, st));
+    TRY(pack_items(n->pack_table, n->n_pack, n->pack_chunks, st));
 
     // TimeEmbedding(t) for every timestep (diffusion_model.py:802-823), float32 throughout
-    TRY(sinusoid_table(n->sin_table, H, n->Tp, H / 2, p.sinusoid_freq, st));
+    if (!n->sin_built) TRY(sinusoid_table(n->sin_table, H, n->Tp, H / 2, p.sinusoid_freq, st));
+    n->sin_built = true;
     adcdiff_gemm_args g = gemm_args(ADCDIFF_F32, n->Tp, 0, 4 * H);
     g.nseg = 1; g.A[0] = n->sin_table; g.lda[0] = H; g.K[0] = H; g.W = p.time_lin1_w; g.ldw = H; g.bias = p.time_lin1_b;
     g.out_f32 = n->te_pre; g.ldo_f32 = 4 * H;   // pre-activation kept for the training step's backward

@@ -20,6 +20,19 @@ int temb_silu(const float* te_table, int ldt, int table_rows, const int64_t* t_r
 int cast_pack(const float* src, int lds_, int dtype, void* dst, int ldd, int col0, int rows, int cols, hipStream_t stream);
 int add_vec(const float* a, const float* b, float* out, int n, hipStream_t stream);
 
+// One entry of the batched weight packing: dst[r * ldd + col0 + c] = (dtype) (src[r * cols + c] + (add ? add[r * cols + c] : 0)),
+// r * cols + c < numel; cols, ldd, col0 multiples of 4.  chunk_start = PACK_CHUNK-element chunks of all earlier entries.
+struct PackItem {
+    const float* src;
+    const float* add;
+    void* dst;
+    int cols, ldd, col0, dtype;
+    long long numel, chunk_start;
+};
+constexpr int PACK_CHUNK = 2048;
+constexpr int PACK_MAX_ITEMS = 128;
+int pack_items(const PackItem* items_dev, int n_items, long long total_chunks, hipStream_t stream);
+
 static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static inline int num_groups(int dim) {   // diffusion_model.py:723-730, 840-847
@@ -82,6 +95,10 @@ struct adcdiff_unet {
     void *w_out, *w_c0, *w_c2;
     size_t arena_used;
     bool packed;
+    adcdiff::PackItem* pack_table;      // device copy of the packing entries (in the arena), n_pack entries, pack_chunks chunks
+    int n_pack;
+    long long pack_chunks;
+    bool sin_built;            // the sinusoid table depends on constants only: built by the first pack
     bool fused;     // every GroupNorm can be applied in a producing GEMM's epilogue
     bool fold;      // fused, and the output GEMM can apply the sampler's update and encoder.0's norm1 of the next step
     adcdiff::Tape tape;
