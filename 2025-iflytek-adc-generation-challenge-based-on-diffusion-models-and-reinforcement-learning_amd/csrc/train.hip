@@ -240,6 +240,20 @@ static int cast_transpose(const InT* src, long lds_, int rows, int rows_pad, int
     return check_launch("cast_transpose");
 }
 
+// float32 [rows, cols] -> bf16 row-major, column sums accumulated into colsum and copied to colsum2 (a bias that two layers
+// share).  (A variant with 16-byte loads, both sums as atomics of one kernel and the per-timestep scatter folded in measured
+// slower on the same box: atomics count in vmcnt in issue order, so loads wait for the atomics issued before them.)
+static int cast_rows(const float* src, long lds_, int rows, int rows_pad, int cols, void* dst, long ldd, float* colsum, float* colsum2,
+                     hipStream_t st) {
+    TRY(cast_transpose<float>(src, lds_, rows, rows_pad, cols, ADCDIFF_BF16, dst, ldd, nullptr, 0, colsum, st));
+    if (colsum2) {
+        TimingScope ts(ADCDIFF_KIND_OTHER, 1, 0, 0, 0.0, (double)cols * 8.0, st);
+        hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, colsum, colsum2, (long)cols, 0);
+        return check_launch("copy_f32");
+    }
+    return ADCDIFF_OK;
+}
+
 // transposes an operand-typed [rows, cols] activation into [cols, rows_pad]
 static int transpose_op(const void* src, long lds_, int rows, int rows_pad, int cols, int dtype, void* dst_t, hipStream_t st) {
     if (dtype == ADCDIFF_BF16)
@@ -461,7 +475,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
     const bool direct = dt == ADCDIFF_BF16 && B % 64 == 0 && direct_enabled();
     if (direct) {
         void* dE_rm = ws.take((size_t)Bp * O * e);
-        RUN(cast_transpose<float>(d_eps, lde, B, Bp, O, dt, dE_rm, O, nullptr, 0, gr->out_b, st));
+        RUN(cast_rows(d_eps, lde, B, Bp, O, dE_rm, O, gr->out_b, nullptr, st));
         TRY(gemm_dw_direct(dE_rm, O, tp.a_out, H, O, H, B, gr->out_w, H, H, ws, dry, st));
         float* d_a = (float*)ws.take((size_t)Bp * H * 4);
         RUN(gemm_tr(false, dE_rm, O, n->w_out, H, d_a, H, Bp, H, O, 1, 0, st));
@@ -498,8 +512,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         if (direct) {
             // (1) dO in bf16; its column sums are d(linear2.bias) (= d(residual_proj.bias))
             void* dY = ws.take((size_t)Bp * cout * e);
-            RUN(cast_transpose<float>(dO[i], cout, B, Bp, cout, dt, dY, cout, nullptr, 0, g.linear2_b, st));
-            if (b.has_res) RUN(copy_f32(g.linear2_b, g.residual_b, cout, 0, st));
+            RUN(cast_rows(dO[i], cout, B, Bp, cout, dY, cout, g.linear2_b, b.has_res ? g.residual_b : nullptr, st));
             // (2) d(linear2.weight) = dO^T a2; (3) d(residual_proj.weight) = dO^T x, part by part
             TRY(gemm_dw_direct(dY, cout, bt.a2, cout, cout, cout, B, g.linear2_w, cout, cout, ws, dry, st));
             if (b.has_res) {
@@ -519,8 +532,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             TRY(gn_silu_bwd(bt.h1, cout, d_both, n2, B, cout, b.g2, q.norm2_w, q.norm2_b, tp.drop_p, tp.drop_seed, (uint32_t)i, 0, nullptr, 0, d_h1,
                             cout, 0, g.norm2_w, g.norm2_b, ws, dry, st));
             // (6) d(h1) in bf16: column sums are d(linear1.bias) = d(time_proj.bias); (7) rows go to the timestep table
-            RUN(cast_transpose<float>(d_h1, cout, B, Bp, cout, dt, dY, cout, nullptr, 0, g.linear1_b, st));
-            RUN(copy_f32(g.linear1_b, g.time_proj_b, cout, 0, st));
+            RUN(cast_rows(d_h1, cout, B, Bp, cout, dY, cout, g.linear1_b, g.time_proj_b, st));
             {
                 const long total = (long)B * cout;
                 if (!dry) {
