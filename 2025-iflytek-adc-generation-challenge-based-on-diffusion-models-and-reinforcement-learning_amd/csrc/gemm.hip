@@ -1094,10 +1094,10 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     p.out_op = a.out_op; p.ldo_op = a.ldo_op;
     const double esz = esize;
     const double nout = (a.out_f32 ? 4.0 : 0.0) + esz * ((a.out_op ? 1 : 0) + a.n_gn);
-    // Kernel choice for bf16, from A/B timings of the kernels on the denoiser's layer shapes at M = 65536: the
-    // 256 x 256 kernel (one workgroup per CU, prefetch under the MFMAs, rolled epilogue) wins once the K loop is long
-    // enough to amortise its exposed prologue / epilogue, and where the epilogue is the larger part (three outputs from
-    // K >= 768); the 128-row kernel (3-4 workgroups per CU) wins elsewhere.
+    // Kernel choice for bf16, from A/B timings of the kernels on the denoiser's layer shapes at M = 65536 (interleaved in one
+    // process): the 256 x 256 kernel (one workgroup per CU, prefetch under the MFMAs, rolled epilogue) wins or ties on every
+    // shape with at least eight K tiles, by up to 27 % on the 256-wide layers; the 128-row kernel (3-4 workgroups per CU)
+    // keeps the K = 256 layers and everything with too few 256-tiles to fill the chip.
     bool big = false, pipelined = false;
     // measurement aid: ADCDIFF_GEMM_RING=1 selects the ring main loop for every 256-tile launch (tile_hint 2561 does per call);
     // the two-group phased loop is the default: same cycles per tile within 1 %, but the chip holds a higher clock on it
@@ -1105,7 +1105,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     if (a.dtype == ADCDIFF_BF16 && a.M % 256 == 0 && a.N % 256 == 0 && a.tile_hint != 128) {
         static const int forced = [] { const char* e = getenv("ADCDIFF_GEMM_TILE"); return e ? atoi(e) : 0; }();   // measurement aid
         const bool enough_tiles = forced != 128 && (long)(a.M / 256) * (a.N / 256) * p.ksplit >= 192;
-        const bool long_k = kslice >= 2048 || (nout >= 3.0 * esz && kslice >= 768);
+        const bool long_k = kslice >= 512;
         big = forced == 256 || forced == 2561 || a.tile_hint == 256 || a.tile_hint == 2561 || a.tile_hint == 2560 || (enough_tiles && long_k);
         pipelined = a.tile_hint == 2561 || (a.tile_hint != 2560 && pipe_default);
     }

@@ -135,6 +135,16 @@ def summarize_records(records, dtype, units, algo_flop_per_unit, workload):
             "share_of_window": round(dom_ms / max(1e-9, window_ms), 3),
             "timing": "hipEvent in front of every launch on the launch stream, span to the next launch's event, minus the per-event cost "
                       "measured against the same window between one event pair"}
+    # the dominant kernel by layer shape (it runs layers of very different arithmetic intensity): the three shapes that take the most time
+    shapes = {}
+    for r in dom:
+        k = (r["N"], r["K"])
+        a = shapes.setdefault(k, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += r["ms"]; a[2] += r["flops"]
+    main["by_shape"] = [{"N": k[0], "K": k[1], "launches": a[0], "avg_launch_ms": round(a[1] / a[0], 4),
+                         "achieved": round(a[2] / (a[1] * 1e-3) / 1e12, 1), "frac": round(a[2] / (a[1] * 1e-3) / 1e12 / peak, 4),
+                         "share_of_window": round(a[1] / max(1e-9, window_ms), 3)}
+                        for k, a in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:3]]
     tr = measured_traffic(dom_key, workload)
     if tr:
         main["traffic"], main["traffic_source"] = tr[0], "profiles/" + tr[1]
