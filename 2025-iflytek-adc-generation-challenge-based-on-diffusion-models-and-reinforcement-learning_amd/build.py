@@ -6,6 +6,7 @@ shared object travels to the GPU box with the source tree.
 import os
 import shutil
 import subprocess
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -23,7 +24,11 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "unet_plan.h"), os.path.join(os.path.dirname(HERE), "include", "adcdiff.h")]
+    # the assembly main loop of the 4-wave GEMM is generated (register-allocated by hand in the generator)
+    gen, inc = os.path.join(CSRC, "gen_w4_mainloop.py"), os.path.join(CSRC, "w4_mainloop.inc")
+    if force or _stale(inc, [gen]):
+        subprocess.run([sys.executable, gen, inc], check=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "unet_plan.h"), inc, os.path.join(os.path.dirname(HERE), "include", "adcdiff.h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []

@@ -139,7 +139,7 @@ struct Epilogue {
     static constexpr int XCH_BYTES = 4 * XB * 4;    // [step parity][GroupNorm output]
     static constexpr int EXTRA_BYTES = PRM_BYTES + XCH_BYTES;
     typedef float acc_t __attribute__((ext_vector_type(NACC)));
-    static_assert(NCHUNK >= 1 && NCHUNK <= 4 && CH % TS == 0 && (LPR == 8 || LPR == 4), "unsupported epilogue geometry");
+    static_assert(NCHUNK >= 1 && NCHUNK <= 4 && CH % TS == 0 && (LPR == 16 || LPR == 8 || LPR == 4), "unsupported epilogue geometry");
 
     // Called by all threads at kernel start: column-dependent vectors of this block's BN columns -> LDS.
     static __device__ __forceinline__ void stage_params(const GemmParams& p, int n0, int tid, float* prm) {
@@ -160,9 +160,12 @@ struct Epilogue {
         }
     }
 
+    // SiLU(GroupNorm(v)) of the lane's 8 columns in the operand type: the arithmetic only, no store and no lane-dependent
+    // branch, so that several rows can be computed in one basic block and interleaved by the scheduler (gn_multi)
+    typedef T outv_t __attribute__((ext_vector_type(8)));
     template <int GS>
-    static __device__ __forceinline__ void gn_store(const float (&v)[8], const float (&gam)[8], const float (&bet)[8], T* dst, float eps,
-                                                    bool live, float* xch, int wave, int rr, int cg) {
+    static __device__ __forceinline__ void gn_compute(const float (&v)[8], const float (&gam)[8], const float (&bet)[8], outv_t& out, float eps,
+                                                      float* xch, int wave, int rr, int cg) {
         float y[8];
         if constexpr (GS == 4) {
 #pragma unroll
@@ -176,7 +179,12 @@ struct Epilogue {
                 for (int k = 0; k < 4; ++k) y[4 * h + k] = silu_out<T>((v[4 * h + k] - mean) * rstd * gam[4 * h + k] + bet[4 * h + k]);
             }
         } else {
-            constexpr int IN_WAVE = GS <= WTN ? GS : WTN;   // channels of the group inside this wave
+            // A group of 128 channels is always summed as two halves of 64 that are merged with the pairwise update, so that
+            // every tiling produces the same bits: the halves sit in two waves (WTN = 64, exchange through LDS) or in the two
+            // 8-lane halves of a 16-lane row of one wave (WTN = 128, exchange with a DPP rotate by 8).
+            constexpr bool DPP_SPLIT = WTN == 128 && GS == 128;
+            constexpr bool LDS_SPLIT = !DPP_SPLIT && GS > WTN;
+            constexpr int IN_WAVE = DPP_SPLIT ? 64 : GS <= WTN ? GS : WTN;   // channels summed inside the wave before any merge
             constexpr int LANES = IN_WAVE / 8;
             if constexpr (BF) {
                 // bf16 outputs: the same two-pass statistics on pairs of elements (v_pk_add / v_pk_mul / v_pk_fma_f32 do two
@@ -194,10 +202,15 @@ struct Epilogue {
 #pragma unroll
                 for (int i = 1; i < 4; ++i) q2 = q2 + d2[i] * d2[i];
                 float q = group_sum<LANES>(q2[0] + q2[1]);
-                if constexpr (GS > WTN) {
-                    if (cg == 0) { xch[(wave * RPS + rr) * 2] = mean; xch[(wave * RPS + rr) * 2 + 1] = q; }
-                    __syncthreads();
-                    const float om = xch[((wave ^ 1) * RPS + rr) * 2], oq = xch[((wave ^ 1) * RPS + rr) * 2 + 1];
+                if constexpr (LDS_SPLIT || DPP_SPLIT) {
+                    float om, oq;
+                    if constexpr (LDS_SPLIT) {
+                        if (cg == 0) { xch[(wave * RPS + rr) * 2] = mean; xch[(wave * RPS + rr) * 2 + 1] = q; }
+                        __syncthreads();
+                        om = xch[((wave ^ 1) * RPS + rr) * 2]; oq = xch[((wave ^ 1) * RPS + rr) * 2 + 1];
+                    } else {
+                        om = dpp_f<0x128>(mean); oq = dpp_f<0x128>(q);   // row_ror:8 = the other half of the 16-lane row
+                    }
                     const float delta = om - mean;
                     q = q + oq + delta * delta * (0.5f * IN_WAVE);
                     const float shift = -0.5f * delta;   // old mean - merged mean
@@ -216,7 +229,7 @@ struct Epilogue {
                     o[2 * i] = (bf16_t)o2[0];
                     o[2 * i + 1] = (bf16_t)o2[1];
                 }
-                if (live) *reinterpret_cast<bf16x8*>(dst) = o;
+                out = o;
                 return;
             }
             float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
@@ -226,11 +239,16 @@ struct Epilogue {
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const float d = v[k] - mean; q += d * d; }
             q = group_sum<LANES>(q);
-            if constexpr (GS > WTN) {
-                // the other half of the group lives in wave ^ 1: exchange (mean, M2) and merge
-                if (cg == 0) { xch[(wave * RPS + rr) * 2] = mean; xch[(wave * RPS + rr) * 2 + 1] = q; }
-                __syncthreads();
-                const float om = xch[((wave ^ 1) * RPS + rr) * 2], oq = xch[((wave ^ 1) * RPS + rr) * 2 + 1];
+            if constexpr (LDS_SPLIT || DPP_SPLIT) {
+                // the other half of the group lives in wave ^ 1 (or in the other 8 lanes of the row): exchange (mean, M2) and merge
+                float om, oq;
+                if constexpr (LDS_SPLIT) {
+                    if (cg == 0) { xch[(wave * RPS + rr) * 2] = mean; xch[(wave * RPS + rr) * 2 + 1] = q; }
+                    __syncthreads();
+                    om = xch[((wave ^ 1) * RPS + rr) * 2]; oq = xch[((wave ^ 1) * RPS + rr) * 2 + 1];
+                } else {
+                    om = dpp_f<0x128>(mean); oq = dpp_f<0x128>(q);
+                }
                 const float delta = om - mean;
                 q = q + oq + delta * delta * (0.5f * IN_WAVE);
                 mean = 0.5f * (mean + om);
@@ -239,7 +257,47 @@ struct Epilogue {
 #pragma unroll
             for (int k = 0; k < 8; ++k) y[k] = silu_out<T>((v[k] - mean) * rstd * gam[k] + bet[k]);
         }
-        if (live) store8<T>(dst, y);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = (T)y[k];
+    }
+
+    template <int GS>
+    static __device__ __forceinline__ void gn_store(const float (&v)[8], const float (&gam)[8], const float (&bet)[8], T* dst, float eps,
+                                                    bool live, float* xch, int wave, int rr, int cg) {
+        outv_t o;
+        gn_compute<GS>(v, gam, bet, o, eps, xch, wave, rr, cg);
+        if (live) *reinterpret_cast<outv_t*>(dst) = o;
+    }
+
+    // R rows at once: R independent dependency chains in one basic block (a wave that is alone on its SIMD has nothing else to
+    // fill the latency of the DPP sums and of v_exp / v_rcp with), the stores behind them.  Not for groups that span two waves.
+    template <int GS, int R>
+    static __device__ __forceinline__ void gn_multi(const float (&v)[R][8], const float (&gam)[8], const float (&bet)[8], T* const (&dst)[R],
+                                                    float eps, const bool (&live)[R], int wave, int rr, int cg) {
+        static_assert(GS <= WTN, "gn_multi: the group must lie inside the wave");
+        outv_t o[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) gn_compute<GS>(v[r], gam, bet, o[r], eps, nullptr, wave, rr, cg);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (live[r]) *reinterpret_cast<outv_t*>(dst[r]) = o[r];
+    }
+
+    template <int R>
+    static __device__ __forceinline__ void gn_dispatch_multi(int gs, const float (&v)[R][8], const float (&gam)[8], const float (&bet)[8],
+                                                             T* const (&dst)[R], float eps, const bool (&live)[R], int wave, int rr, int cg) {
+        switch (gs) {   // workgroup-uniform
+            case 4: gn_multi<4, R>(v, gam, bet, dst, eps, live, wave, rr, cg); break;
+            case 8: gn_multi<8, R>(v, gam, bet, dst, eps, live, wave, rr, cg); break;
+            case 16: gn_multi<16, R>(v, gam, bet, dst, eps, live, wave, rr, cg); break;
+            case 32: gn_multi<32, R>(v, gam, bet, dst, eps, live, wave, rr, cg); break;
+            case 64:
+                if constexpr (WTN >= 64) gn_multi<64, R>(v, gam, bet, dst, eps, live, wave, rr, cg);
+                break;
+            default:
+                if constexpr (WTN >= 128) gn_multi<128, R>(v, gam, bet, dst, eps, live, wave, rr, cg);
+                break;
+        }
     }
 
     static __device__ __forceinline__ void gn_dispatch(int gs, const float (&v)[8], const float (&gam)[8], const float (&bet)[8], T* dst,
@@ -251,7 +309,7 @@ struct Epilogue {
             case 32: gn_store<32>(v, gam, bet, dst, eps, live, xch, wave, rr, cg); break;
             case 64: gn_store<64>(v, gam, bet, dst, eps, live, xch, wave, rr, cg); break;
             default:
-                if constexpr (WTN == 64) gn_store<128>(v, gam, bet, dst, eps, live, xch, wave, rr, cg);
+                if constexpr (WTN >= 64) gn_store<128>(v, gam, bet, dst, eps, live, xch, wave, rr, cg);
                 break;
         }
     }
@@ -308,41 +366,59 @@ struct Epilogue {
         }
     }
 
-    // One step: RPS rows of the staged chunk, a lane owning 8 contiguous columns of one row.
-    template <bool PRM_IN_REGS>
-    static __device__ __forceinline__ void step(const GemmParams& p, const float* stage, const float* prm, float* xch_base, int h, int st,
-                                                int step_id, int m0, int wm, int wave, int rr, int cg, int bcol, long col,
-                                                const float (&cb)[8], const float (&g0)[8], const float (&b0)[8],
-                                                const float (&g1)[8], const float (&b1)[8]) {
+    // One step: RPS rows of the staged chunk, a lane owning 8 contiguous columns of one row.  step_load fetches what the step
+    // reads (the staged accumulators, the row's bias-table row, the residual); step_finish does the arithmetic and the stores.
+    // A wave that is alone on its SIMD runs the loads of several steps before the first finish (run<ROLLED, U>): nothing
+    // else on the SIMD would cover their latency.
+    struct StepIn {
+        float v[8], rb[8];
+        bf16x8 res_bf;
+        float res_f[8];
+    };
+    static __device__ __forceinline__ void step_load(const GemmParams& p, const float* stage, int h, int st, int m0, int wm, int rr, int cg,
+                                                     long col, StepIn& in) {
         const T* const resp = reinterpret_cast<const T*>(p.residual);
         const bool row_rb = p.rowbias != nullptr && (p.rowbias_idx != nullptr || p.ldrb != 0);
         const int crow = st * RPS + rr;
         const long row = m0 + wm * WTM + h * CH + crow;
-        const bool live = row < p.m_valid;
-        const long lrow = live ? row : 0;    // dead rows read row 0's side inputs (always valid) and store nothing
-        float v[8];
-        load8(stage + crow * LDW + cg * 8, v);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += cb[k];
+        const long lrow = row < p.m_valid ? row : 0;    // dead rows read row 0's side inputs (always valid) and store nothing
+        load8(stage + crow * LDW + cg * 8, in.v);
         if (row_rb) {
             long ridx = p.rowbias_idx ? (long)p.rowbias_idx[lrow] : lrow;
             if (p.rowbias_rows > 0) ridx = ridx < 0 ? 0 : ridx >= p.rowbias_rows ? p.rowbias_rows - 1 : ridx;   // never read outside the table
-            float t[8];
-            load8(p.rowbias + ridx * p.ldrb + col, t);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += t[k];
+            load8(p.rowbias + ridx * p.ldrb + col, in.rb);
         }
         if (resp) {
             const T* rp = resp + lrow * p.ldr + col;
+            if constexpr (BF) in.res_bf = *reinterpret_cast<const bf16x8*>(rp);
+            else load8(reinterpret_cast<const float*>(rp), in.res_f);
+        }
+    }
+
+    template <bool PRM_IN_REGS>
+    static __device__ __forceinline__ void step_finish(const GemmParams& p, const StepIn& in, const float* prm, float* xch_base, int h, int st,
+                                                       int step_id, int m0, int wm, int wave, int rr, int cg, int bcol, long col,
+                                                       const float (&cb)[8], const float (&g0)[8], const float (&b0)[8],
+                                                       const float (&g1)[8], const float (&b1)[8]) {
+        const bool row_rb = p.rowbias != nullptr && (p.rowbias_idx != nullptr || p.ldrb != 0);
+        const int crow = st * RPS + rr;
+        const long row = m0 + wm * WTM + h * CH + crow;
+        const bool live = row < p.m_valid;
+        const long lrow = live ? row : 0;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = in.v[k] + cb[k];
+        if (row_rb) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += in.rb[k];
+        }
+        if (p.residual) {
             if constexpr (BF) {
-                const bf16x8 t = *reinterpret_cast<const bf16x8*>(rp);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+                for (int e = 0; e < 8; ++e) v[e] += (float)in.res_bf[e];
             } else {
-                float t[8];
-                load8(reinterpret_cast<const float*>(rp), t);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += t[k];
+                for (int k = 0; k < 8; ++k) v[k] += in.res_f[k];
             }
         }
         if (p.act == 1) {
@@ -377,12 +453,84 @@ struct Epilogue {
         }
     }
 
+    // U consecutive steps finished together (U rows per lane): side inputs added row by row in the order of step_finish, then
+    // every output of the U rows from one basic block.  For kernels whose GroupNorm groups never span two waves.
+    template <int U>
+    static __device__ __forceinline__ void finish_multi(const GemmParams& p, const StepIn (&in)[U], const float* prm, int h, int st0,
+                                                        int m0, int wm, int wave, int rr, int cg, int bcol, long col, const float (&cb)[8]) {
+        const bool row_rb = p.rowbias != nullptr && (p.rowbias_idx != nullptr || p.ldrb != 0);
+        float v[U][8];
+        long row[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            row[u] = m0 + wm * WTM + h * CH + (st0 + u) * RPS + rr;
+            live[u] = row[u] < p.m_valid;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[u][k] = in[u].v[k] + cb[k];
+        }
+        if (row_rb) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[u][k] += in[u].rb[k];
+        }
+        if (p.residual) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[u][k] += BF ? (float)in[u].res_bf[k] : in[u].res_f[k];
+        }
+        if (p.act == 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[u][k] = silu_f(v[u][k]);
+        }
+        if (p.upd.kind != 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) apply_update(p.upd, v[u], live[u] ? row[u] : 0, col);
+        }
+        if (p.out_f32) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (live[u]) store8<float>(p.out_f32 + (long)blockIdx.y * p.split_out_stride + row[u] * p.ldo_f32 + col, v[u]);
+        }
+        if (p.out_op) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (live[u]) store8<T>(reinterpret_cast<T*>(p.out_op) + row[u] * p.ldo_op + col, v[u]);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (g < p.n_gn) {
+                float gam[8], bet[8];
+                load8(prm + (1 + 2 * g) * BN + bcol, gam);
+                load8(prm + (2 + 2 * g) * BN + bcol, bet);
+                T* dst[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) dst[u] = reinterpret_cast<T*>(p.gn[g].out) + row[u] * p.gn[g].ldo + col;
+                gn_dispatch_multi<U>(p.gn[g].gs, v, gam, bet, dst, p.eps, live, wave, rr, cg);
+            }
+        }
+    }
+
+    template <bool PRM_IN_REGS>
+    static __device__ __forceinline__ void step(const GemmParams& p, const float* stage, const float* prm, float* xch_base, int h, int st,
+                                                int step_id, int m0, int wm, int wave, int rr, int cg, int bcol, long col,
+                                                const float (&cb)[8], const float (&g0)[8], const float (&b0)[8],
+                                                const float (&g1)[8], const float (&b1)[8]) {
+        StepIn in;
+        step_load(p, stage, h, st, m0, wm, rr, cg, col, in);
+        step_finish<PRM_IN_REGS>(p, in, prm, xch_base, h, st, step_id, m0, wm, wave, rr, cg, bcol, col, cb, g0, b0, g1, b1);
+    }
+
     // smem_epi: NWAVE private staging regions (reusing the main loop's LDS); prm / xch: behind the main loop's LDS.
     // ROLLED: the chunk and step loops stay loops, so the step body exists once per GroupNorm variant and is re-executed
     // from the instruction cache -- for the one-workgroup-per-CU kernel, whose waves otherwise all fetch ~100 KB of
     // straight-line code cold.  Only the accumulator -> LDS copy needs compile-time register indices, hence the switch.
     // Unrolled (the kernels with 3-4 workgroups per CU): steps overlap each other's loads, parameters sit in registers.
-    template <bool ROLLED>
+    template <bool ROLLED, int U = 1>
     static __device__ __forceinline__ void run(const acc_t (&acc)[TM][TN], const GemmParams& p, int m0, int n0, int wm, int wn, int wave,
                                                int lane, float* smem_epi, float* prm, float* xch_base) {
         float* const stage = smem_epi + wave * (CH * LDW);
@@ -409,9 +557,20 @@ struct Epilogue {
                     case 2: stage_chunk<2>(acc, stage, crow0, ccol); break;
                     default: stage_chunk<3>(acc, stage, crow0, ccol); break;
                 }
+                if constexpr (U == 1) {
 #pragma unroll 1
-                for (int st = 0; st < NSTEP; ++st, ++step_id)
-                    step<false>(p, stage, prm, xch_base, h, st, step_id, m0, wm, wave, rr, cg, bcol, col, cb, g0, b0, g1, b1);
+                    for (int st = 0; st < NSTEP; ++st, ++step_id)
+                        step<false>(p, stage, prm, xch_base, h, st, step_id, m0, wm, wave, rr, cg, bcol, col, cb, g0, b0, g1, b1);
+                } else {
+                    static_assert(NSTEP % U == 0, "steps per chunk must be a multiple of the load batch");
+#pragma unroll 1
+                    for (int st = 0; st < NSTEP; st += U, step_id += U) {
+                        StepIn in[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) step_load(p, stage, h, st + u, m0, wm, rr, cg, col, in[u]);
+                        finish_multi<U>(p, in, prm, h, st, m0, wm, wave, rr, cg, bcol, col, cb);
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -695,7 +854,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmParams p
 #define ADCDIFF_P_WAIT(P)                                                                                           \
     do {                                                                                                           \
         const int rem_ = nreg - 3 - (P);                                                                           \
-        if (rem_ >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                            \
+        if (rem_ >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                       \
         else if (rem_ == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                       \
         else if (rem_ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                       \
         else if (rem_ == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                       \
@@ -948,6 +1107,92 @@ __global__ __launch_bounds__(512, 2) void gemm256r_bf16_kernel(const GemmParams 
 #endif
 }
 
+// ---- 256 x 256 tile, 4 waves (2 x 2, 128 x 128 per wave), bf16, ONE wave per SIMD, accumulators in a[0:255] ----------
+// The main loop is hand-allocated assembly (w4_mainloop.inc, generated by gen_w4_mainloop.py, which documents the register
+// map, the LDS image, the phase protocol and the L2 prefetch): hipcc spills hundreds of registers on a 512-register loop.
+// This wrapper computes the loop's inputs, pins them and the 64 accumulators to the registers the loop names, and runs the
+// shared epilogue on the result.  K order per accumulator = the other kernels' (32-wide steps in order), so results are
+// bit-identical between the tilings.  Not for split-K launches.
+#include "w4_mainloop.inc"
+
+template <int EPI_U>
+__global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams p) {
+    typedef bf16_t T;
+    constexpr int BN = 256, WTM = 128, WTN = 128, TM = 8, TN = 8, STAGE_BYTES = 65536;
+    typedef Epilogue<T, 256, BN, WTM, WTN, TM, TN> Epi;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const prm = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);
+    float* const xch = prm + 5 * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int nidx = bid % p.ntn;
+    const int m0 = (bid / p.ntn) * 256, n0 = nidx * BN;
+    Epi::stage_params(p, n0, tid, prm);
+
+    // Loader role: waves 0, 1 stage the A rows 128 (wave & 1) .. + 127 of the tile, waves 2, 3 the W rows.  Per K segment
+    // {base, row pitch, K tiles, addressable bytes}; W is one segment.  The descriptor's size stops any stray access.
+    const bool loads_a = wave < 2;
+    const int half = wave & 1;
+    int seg_lo[3], seg_hi[3], seg_ld[3], seg_kt[3], seg_nrec[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const unsigned ld = loads_a ? (unsigned)p.lda[s] * 2u : (unsigned)p.ldw * 2u;
+        const int kt = loads_a ? p.ktiles[s] : s == 0 ? p.nt_total : 0;
+        const unsigned long long base = loads_a ? (unsigned long long)p.A[s] + (unsigned long long)(m0 + half * 128) * ld
+                                                : (unsigned long long)p.W + (unsigned long long)(n0 + half * 128) * ld;
+        seg_lo[s] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+        seg_hi[s] = __builtin_amdgcn_readfirstlane((int)((unsigned)(base >> 32) & 0xffffu));
+        seg_ld[s] = __builtin_amdgcn_readfirstlane((int)ld);
+        seg_kt[s] = __builtin_amdgcn_readfirstlane(kt);
+        seg_nrec[s] = __builtin_amdgcn_readfirstlane(kt > 0 ? (int)(127u * ld + (unsigned)kt * 128u) : 0);
+    }
+    const int s_nt = __builtin_amdgcn_readfirstlane(p.nt_total);
+    const int s_dst = __builtin_amdgcn_readfirstlane((int)(lds0 + (loads_a ? 0u : 32768u) + (unsigned)half * 16384u));
+    // fragment read offsets inside a stage: row 16 n + frow of the wave's block, k chunk 4 h + fchunk, chunk ^ ((row >> 1) & 7)
+    const int frow = lane & 15, fchunk = lane >> 4, fx = (frow >> 1) & 7;
+    const int v_aoff0 = (int)lds0 + (wm * WTM + frow) * 128 + ((fchunk ^ fx) << 4);
+    const int v_aoff1 = (int)lds0 + (wm * WTM + frow) * 128 + (((4 + fchunk) ^ fx) << 4);
+    const int v_boff0 = (int)lds0 + 32768 + (wn * WTN + frow) * 128 + ((fchunk ^ fx) << 4);
+    const int v_boff1 = (int)lds0 + 32768 + (wn * WTN + frow) * 128 + (((4 + fchunk) ^ fx) << 4);
+    // LDS-DMA source offsets: piece j of the wave = its rows 8 j .. 8 j + 7, lane -> row 8 j + (lane >> 3), chunk position
+    // lane & 7, which holds chunk (lane & 7) ^ ((row >> 1) & 7) = (lane & 7) ^ ((4 j + (lane >> 4)) & 7): two offsets, by the parity of j
+    // Prefetch offsets: the ntn workgroups of a tile row split its 256 A rows (share rows each, inside ONE loader wave's half);
+    // the lanes of that wave point at the share's lines (64 / share consecutive K tiles deep), every other wave at one line.
+    const int share = p.ntn >= 2 ? 256 / p.ntn : 128, prow0 = p.ntn >= 2 ? nidx * share : half * 128;
+    const bool pf_wave = loads_a && (prow0 >> 7) == half;
+    const int pf_row = (prow0 & 127) + (share >= 64 ? lane : lane % share);   // a share of 128 rows is covered by half (64 lanes)
+    const int pf_k = share >= 64 ? 0 : (lane / share) * 128;
+    int v_src0[3], v_src1[3], v_pf[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const unsigned ld = (unsigned)seg_ld[s];
+        v_src0[s] = (int)((unsigned)(lane >> 3) * ld + (unsigned)(((lane & 7) ^ (lane >> 4)) * 16));
+        v_src1[s] = (int)((unsigned)(lane >> 3) * ld + (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) * 16));
+        v_pf[s] = pf_wave ? (int)((unsigned)pf_row * ld + (unsigned)pf_k) : 0;
+    }
+
+    f32x4 acc[TM][TN];
+    asm volatile(ADCDIFF_W4_MAINLOOP_ASM
+                 : ADCDIFF_W4_OUTS(acc)
+                 : "{s40}"(seg_lo[0]), "{s41}"(seg_hi[0]), "{s42}"(seg_ld[0]), "{s43}"(seg_kt[0]), "{s44}"(seg_nrec[0]),
+                   "{s45}"(seg_lo[1]), "{s46}"(seg_hi[1]), "{s47}"(seg_ld[1]), "{s48}"(seg_kt[1]), "{s49}"(seg_nrec[1]),
+                   "{s50}"(seg_lo[2]), "{s51}"(seg_hi[2]), "{s52}"(seg_ld[2]), "{s53}"(seg_kt[2]), "{s54}"(seg_nrec[2]),
+                   "{s55}"(s_nt), "{s56}"(s_dst),
+                   "{v130}"(v_aoff0), "{v131}"(v_boff0), "{v132}"(v_aoff1), "{v133}"(v_boff1),
+                   "{v136}"(v_src0[0]), "{v137}"(v_src1[0]), "{v138}"(v_src0[1]), "{v139}"(v_src1[1]), "{v140}"(v_src0[2]), "{v141}"(v_src1[2]),
+                   "{v144}"(v_pf[0]), "{v145}"(v_pf[1]), "{v146}"(v_pf[2])
+                 : ADCDIFF_W4_CLOBBERS);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last prefetch loads (their data is never used)
+    __syncthreads();
+    Epi::template run<true, EPI_U>(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
+}
+
 // pipelined = the ring main loop (gemm256r_bf16_kernel), else the two-group phased loop
 static int launch256(const GemmParams& p, bool pipelined, hipStream_t stream) {
     constexpr int smem = 2 * 65536 + Epilogue<bf16_t, 512, 256, 128, 64, 8, 4>::EXTRA_BYTES;
@@ -993,6 +1238,18 @@ static int launch256(const GemmParams& p, bool pipelined, hipStream_t stream) {
     }
 #endif
     return check_launch("gemm256");
+}
+
+template <int EPI_U>
+static int launch256w(const GemmParams& p, hipStream_t stream) {
+    constexpr int smem = 2 * 65536 + Epilogue<bf16_t, 256, 256, 128, 128, 8, 8>::EXTRA_BYTES;
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256w_bf16_kernel<EPI_U>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    GemmParams q = p;
+    q.ntn = p.N / 256;
+    const int grid = (p.M / 256) * q.ntn;
+    hipLaunchKernelGGL(gemm256w_bf16_kernel<EPI_U>, dim3(grid), dim3(256), smem, stream, q);
+    return check_launch("gemm256w");
 }
 
 template <typename T, int BM, int BN, int NSTAGE>
@@ -1106,7 +1363,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         static const int forced = [] { const char* e = getenv("ADCDIFF_GEMM_TILE"); return e ? atoi(e) : 0; }();   // measurement aid
         const bool enough_tiles = forced != 128 && (long)(a.M / 256) * (a.N / 256) * p.ksplit >= 192;
         const bool long_k = kslice >= 512;
-        big = forced == 256 || forced == 2561 || a.tile_hint == 256 || a.tile_hint == 2561 || a.tile_hint == 2560 || (enough_tiles && long_k);
+        big = forced == 256 || forced == 2561 || a.tile_hint == 256 || a.tile_hint == 2561 || a.tile_hint == 2560 || (a.tile_hint >= 2564 && a.tile_hint <= 2568) || (enough_tiles && long_k);
         pipelined = a.tile_hint == 2561 || (a.tile_hint != 2560 && pipe_default);
     }
     // few rows (the float32 batch-4096 case, small generation batches): 64 x 64 tiles give four times the workgroups
@@ -1117,7 +1374,18 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     const int kind = a.dtype == ADCDIFF_F32 ? ADCDIFF_KIND_GEMM_F32 : big ? ADCDIFF_KIND_GEMM_BF16_T256 : ADCDIFF_KIND_GEMM_BF16;
     TimingScope ts(kind, a.M, a.N, ktot, 2.0 * a.M * a.N * ktot,
                    esz * ((double)a.M * ktot + (double)a.N * ktot) + (double)a.M * a.N * (nout + (a.residual ? esz : 0.0)), stream);
-    if (big) return launch256(p, pipelined, stream);
+    if (big) {
+        // the 4-wave kernel with the assembly main loop unless the launch splits K, has a single K tile, or a hint / the
+        // measurement aid ADCDIFF_GEMM_W4=0 asks for one of the 8-wave kernels
+        static const bool w4_default = [] { const char* e = getenv("ADCDIFF_GEMM_W4"); return e ? atoi(e) != 0 : true; }();
+        const bool w4_ok = p.ksplit == 1 && p.nt_total >= 2;
+        const bool w4_hint = a.tile_hint == 2564 || a.tile_hint == 2565 || a.tile_hint == 2566 || a.tile_hint == 2568;
+        const bool w4 = w4_ok && (w4_hint || (w4_default && a.tile_hint != 2560 && a.tile_hint != 2561 && a.tile_hint != 256));
+        // measurement aids: 2565 / 2566 / 2568 = epilogue load batches of 1 / 2 / 8 steps
+        if (w4) return a.tile_hint == 2565 ? launch256w<1>(p, stream) : a.tile_hint == 2566 ? launch256w<2>(p, stream)
+                     : a.tile_hint == 2568 ? launch256w<8>(p, stream) : launch256w<4>(p, stream);
+        return launch256(p, pipelined, stream);
+    }
     // few workgroups: nothing else on the CU hides a tile's load latency, so take the three-stage ring
     const int bn = small ? 64 : wide ? 128 : 64, bm = small ? 64 : 128;
     const long blocks = (long)(a.M / bm) * (a.N / bn) * p.ksplit;

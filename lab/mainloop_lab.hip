@@ -395,6 +395,97 @@ template <int ABL>
     hipLaunchKernelGGL((w4_kernel<ABL>), dim3(grid), dim3(256), smem, st, p);
 }
 
+
+// ---- 4 waves (2 x 2), 128 x 128 per wave, ONE wave per SIMD: the hand-allocated main loop of the product
+// (csrc/gen_w4_mainloop.py: register map and protocol there), with the generator's ablations (V) and source address
+// patterns (PAT: 0 = the real one, 8 rows x 128 B per piece; 1 = every lane the same 16 bytes; 2 = 1 KiB contiguous) ----
+#include "w4_variants.inc"
+#define W4_OUTS ADCDIFF_W4_OUTS(acc)
+#define W4_INS "{s40}"(s_base_lo), "{s41}"(s_base_hi), "{s42}"(s_ld), "{s43}"(s_steps), "{s44}"(s_nrec), \
+               "{s45}"(s_zero), "{s46}"(s_zero), "{s47}"(s_zero), "{s48}"(s_zero), "{s49}"(s_zero), \
+               "{s50}"(s_zero), "{s51}"(s_zero), "{s52}"(s_zero), "{s53}"(s_zero), "{s54}"(s_zero), \
+               "{s55}"(s_steps), "{s56}"(s_dst), \
+               "{v130}"(v_aoff0), "{v131}"(v_boff0), "{v132}"(v_aoff1), "{v133}"(v_boff1), \
+               "{v136}"(v_src0), "{v137}"(v_src1), "{v138}"(v_src0), "{v139}"(v_src1), "{v140}"(v_src0), "{v141}"(v_src1), \
+               "{v144}"(v_pf), "{v145}"(v_pf), "{v146}"(v_pf)
+#define W4_CLOBBERS ADCDIFF_W4_CLOBBERS
+template <int V, int PAT>
+__global__ __launch_bounds__(256, 1) void w4asm_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    int bid = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int m0 = (bid / p.ntn) * 256, n0 = (bid % p.ntn) * 256;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+
+    const bool loads_a = wave < 2;
+    const unsigned ldb = (unsigned)p.K * 2u;
+    // PAT 3: the A loaders read W rows too (every load an L2 hit); PAT 4: source chunks not permuted
+    const unsigned long long base = loads_a && PAT != 3 ? (unsigned long long)(p.A + (long)(m0 + (wave & 1) * 128) * p.K)
+                                                        : (unsigned long long)(p.W + (long)(n0 + (wave & 1) * 128) * p.K);
+    const int prow = lane >> 3, frow = lane & 15, fchunk = lane >> 4, fx = (frow >> 1) & 7;
+    const int s_base_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+    const int s_base_hi = __builtin_amdgcn_readfirstlane((int)((unsigned)(base >> 32) & 0xffffu));
+    const int s_ld = __builtin_amdgcn_readfirstlane((int)ldb);
+    const int s_steps = __builtin_amdgcn_readfirstlane(p.K / 64);
+    const int s_nrec = __builtin_amdgcn_readfirstlane((int)(127u * ldb + (unsigned)p.K * 2u));
+    const int s_zero = __builtin_amdgcn_readfirstlane(0);
+    const int s_dst = __builtin_amdgcn_readfirstlane((int)(lds0 + (loads_a ? 0u : 32768u) + (unsigned)(wave & 1) * 16384u));
+    const int v_aoff0 = (int)lds0 + (wm * 128 + frow) * 128 + ((fchunk ^ fx) << 4);
+    const int v_aoff1 = (int)lds0 + (wm * 128 + frow) * 128 + (((4 + fchunk) ^ fx) << 4);
+    const int v_boff0 = (int)lds0 + 32768 + (wn * 128 + frow) * 128 + ((fchunk ^ fx) << 4);
+    const int v_boff1 = (int)lds0 + 32768 + (wn * 128 + frow) * 128 + (((4 + fchunk) ^ fx) << 4);
+    // piece j of this wave = rows 8 j .. 8 j + 7 of its 128: (row >> 1) & 7 = (4 j + (lane >> 4)) & 7 depends on the parity of j only
+    const int v_src0 = PAT == 1 ? 0 : PAT == 2 ? lane * 16 : PAT == 4 ? (int)((unsigned)prow * ldb + (unsigned)((lane & 7) * 16))
+                                                                        : (int)((unsigned)prow * ldb + (unsigned)(((lane & 7) ^ (lane >> 4)) * 16));
+    const int v_src1 = PAT == 1 ? 0 : PAT == 2 ? lane * 16 : PAT == 4 ? (int)((unsigned)prow * ldb + (unsigned)((lane & 7) * 16))
+                                                                        : (int)((unsigned)prow * ldb + (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) * 16));
+
+    // prefetch share: the p.ntn workgroups of a tile row split its 256 A rows; the rows of this workgroup lie in one wave's half
+    const int nshare = 256 / p.ntn, nidx = bid % p.ntn, prow0 = nidx * nshare;
+    const bool pf_wave = loads_a && (prow0 >> 7) == (wave & 1);
+    const int v_pf = pf_wave ? (int)((unsigned)((prow0 & 127) + lane % nshare) * ldb + (unsigned)(lane / nshare) * 128u) : 0;
+    f32x4 acc[8][8];
+    if constexpr (V == 0) asm volatile(W4LAB_full : W4_OUTS : W4_INS : W4_CLOBBERS);
+    else if constexpr (V == 1) asm volatile(W4LAB_nodma : W4_OUTS : W4_INS : W4_CLOBBERS);
+    else if constexpr (V == 2) asm volatile(W4LAB_noread : W4_OUTS : W4_INS : W4_CLOBBERS);
+    else if constexpr (V == 3) asm volatile(W4LAB_nobar : W4_OUTS : W4_INS : W4_CLOBBERS);
+    else if constexpr (V == 4) asm volatile(W4LAB_nowait : W4_OUTS : W4_INS : W4_CLOBBERS);
+    else if constexpr (V == 5) asm volatile(W4LAB_mfmaonly : W4_OUTS : W4_INS : W4_CLOBBERS);
+    else if constexpr (V == 6) asm volatile(W4LAB_dmafirsthalf : W4_OUTS : W4_INS : W4_CLOBBERS);
+    else if constexpr (V == 7) asm volatile(W4LAB_nopf : W4_OUTS : W4_INS : W4_CLOBBERS);
+    const long long t2 = __builtin_amdgcn_s_memtime();
+
+    bf16_t* C = p.C;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = m0 + wm * 128 + i * 16 + 4 * (lane >> 4) + r;
+                const int col = n0 + wn * 128 + j * 16 + (lane & 15);
+                C[row * p.N + col] = (bf16_t)acc[i][j][r];
+            }
+    if (lane == 0 && p.stamps) {
+        long long* o = p.stamps + ((long)blockIdx.x * 4 + wave) * 4;
+        o[0] = 0; o[1] = t2 - t0; o[2] = __builtin_amdgcn_s_memtime() - t2; o[3] = 0;
+    }
+}
+
+template <int V, int PAT>
+[[maybe_unused]] static void launch_w4asm(const Params& p, hipStream_t st) {
+    constexpr int smem = 4 * 32768;
+    static bool set = false;
+    if (!set) { CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&w4asm_kernel<V, PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); set = true; }
+    const int grid = (p.M / 256) * (p.N / 256);
+    hipLaunchKernelGGL((w4asm_kernel<V, PAT>), dim3(grid), dim3(256), smem, st, p);
+}
+
 __global__ void ref_kernel(const bf16_t* A, const bf16_t* W, float* out, const int* rows, int nrows, int N, int K) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nrows * N) return;
@@ -458,6 +549,19 @@ int main(int argc, char** argv) {
 
     Variant vs[] = {
         {"ring8 (8 waves 128x64)", launch<4, 0>, 8, true},
+        {"w4asm (4 waves 128x128, asm loop)", launch_w4asm<0, 0>, 4, true},
+        {"w4asm no prefetch", launch_w4asm<7, 0>, 4, true},
+        {"w4asm no DMA", launch_w4asm<1, 0>, 4, false},
+        {"w4asm no fragment reads", launch_w4asm<2, 0>, 4, false},
+        {"w4asm no barrier", launch_w4asm<3, 0>, 4, false},
+        {"w4asm no vmcnt wait", launch_w4asm<4, 0>, 4, false},
+        {"w4asm MFMAs only", launch_w4asm<5, 0>, 4, false},
+        {"w4asm DMA in the first half of the phase", launch_w4asm<6, 0>, 4, true},
+        {"w4asm DMA: all lanes one address", launch_w4asm<0, 1>, 4, false},
+        {"w4asm DMA: 1 KiB contiguous", launch_w4asm<0, 2>, 4, false},
+        {"w4asm DMA: every wave loads W rows", launch_w4asm<0, 3>, 4, false},
+        {"w4asm DMA: chunks not permuted", launch_w4asm<0, 4>, 4, false},
+        {"w4asm no vmcnt wait, W rows only", launch_w4asm<4, 3>, 4, false},
     };
     Params p{A, W, C, M, N, K, N / 256, stamps};
     hipEvent_t e0, e1;

@@ -100,10 +100,13 @@ def test_gemm_fused_groupnorm_outputs(dtype, N, gs_pair):
         assert np.array_equal(vop.float().cpu().numpy()[:M - 3], _bf16_round(v32.cpu().numpy())[:M - 3])
 
 
-@pytest.mark.parametrize("Ks", [[64], [128, 64, 192], [512, 1024]])
-def test_gemm_256_tile_kernel_matches_128_tile_kernel(Ks):
-    """The 256 x 256 eight-wave kernel (used for the large layers) against float64 and against the 128-row kernel,
-    with every epilogue output; K = 64 is the single-tile case, the others exercise the prefetch ring and segments."""
+@pytest.mark.parametrize("hint", [256, 2564])
+@pytest.mark.parametrize("Ks", [[64], [128, 64, 192], [512, 1024], [64, 64], [192, 64, 64]])
+def test_gemm_256_tile_kernel_matches_128_tile_kernel(Ks, hint):
+    """The 256 x 256 kernels (used for the large layers; hint 256 = eight waves, 2564 = four waves with the assembly main
+    loop) against float64 and against the 128-row kernel, with every epilogue output; K = 64 is the single-tile case (the
+    four-wave kernel needs two tiles and hands it to the eight-wave one), the others exercise the prefetch and the K
+    segments.  The two 256-tile kernels agree bit for bit: same k order, same GroupNorm sums."""
     rng = np.random.default_rng(sum(Ks))
     M, N = 768, 512
     As = [rng.standard_normal((M, k)).astype(np.float32) for k in Ks]
@@ -117,8 +120,11 @@ def test_gemm_256_tile_kernel_matches_128_tile_kernel(Ks):
     bf = torch.bfloat16
     kw = dict(bias=_t(bias), rowbias=_t(table), rowbias_idx=_t(idx, torch.int64), residual=_t(res, bf), out_op=True,
               gn=[(_t(gam), _t(bet), 16), (_t(gam), _t(bet), 128)], m_valid=M - 9, dtype="bf16")
-    big = ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=256, **kw)
+    big = ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=hint, **kw)
     small = ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=128, **kw)
+    if hint != 256:
+        for b, o in zip(big, ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=256, **kw)):
+            assert torch.equal(b[:M - 9], o[:M - 9])
     v = np.concatenate([_bf16_round(a) for a in As], 1).astype(np.float64) @ _bf16_round(W).astype(np.float64).T + bias + table[idx] + \
         _bf16_round(res)
     assert rel_err(big[0].cpu().numpy()[:M - 9], v[:M - 9]) < 1e-5
@@ -139,11 +145,12 @@ def test_gemm_asymmetric_layout():
         assert np.array_equal(out, _bf16_round(W).T if dtype == "bf16" else W.T)
     M = N = K = 256
     W = (np.arange(N)[:, None] * 3 + np.arange(K)[None, :] * 0.5).astype(np.float32)
-    out = ops.gemm([_t(np.eye(M, K, dtype=np.float32), torch.bfloat16)], _t(W, torch.bfloat16), dtype="bf16", tile_hint=256).cpu().numpy()
-    assert np.array_equal(out, _bf16_round(W).T)
+    for hint in (256, 2564):
+        out = ops.gemm([_t(np.eye(M, K, dtype=np.float32), torch.bfloat16)], _t(W, torch.bfloat16), dtype="bf16", tile_hint=hint).cpu().numpy()
+        assert np.array_equal(out, _bf16_round(W).T)
 
 
-@pytest.mark.parametrize("dtype,M,N,hint", [("bf16", 256, 256, 128), ("bf16", 512, 256, 256), ("bf16", 512, 256, 2561), ("fp32", 128, 128, 0),
+@pytest.mark.parametrize("dtype,M,N,hint", [("bf16", 256, 256, 128), ("bf16", 512, 256, 256), ("bf16", 512, 256, 2561), ("bf16", 512, 256, 2564), ("fp32", 128, 128, 0),
                                             ("bf16", 128, 128, 0)])
 def test_gemm_applies_the_schedule_update_like_the_stand_alone_kernels(dtype, M, N, hint):
     """The sampler's reverse step inside the output GEMM's epilogue: the latent it writes equals, bit for bit, what
