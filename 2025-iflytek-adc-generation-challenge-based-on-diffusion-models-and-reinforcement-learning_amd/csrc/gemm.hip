@@ -190,6 +190,9 @@ struct Epilogue {
                 // bf16 outputs: the same two-pass statistics on pairs of elements (v_pk_add / v_pk_mul / v_pk_fma_f32 do two
                 // lanes' worth per issue slot: the epilogue is VALU-issue bound, ~15 -> ~9 instructions per element), SiLU
                 // through v_exp_f32 / v_rcp_f32 directly
+                // every fused multiply-add is written out and contraction is off: which of two products the compiler fuses into
+                // a sum is otherwise its choice per call site, and this code and gn_multi below must give the same bits
+#pragma clang fp contract(off)
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
                 f32x2 d2[4];
 #pragma unroll
@@ -200,7 +203,7 @@ struct Epilogue {
                 for (int i = 0; i < 4; ++i) d2[i] = d2[i] - mean;
                 f32x2 q2 = d2[0] * d2[0];
 #pragma unroll
-                for (int i = 1; i < 4; ++i) q2 = q2 + d2[i] * d2[i];
+                for (int i = 1; i < 4; ++i) q2 = __builtin_elementwise_fma(d2[i], d2[i], q2);
                 float q = group_sum<LANES>(q2[0] + q2[1]);
                 if constexpr (LDS_SPLIT || DPP_SPLIT) {
                     float om, oq;
@@ -212,17 +215,17 @@ struct Epilogue {
                         om = dpp_f<0x128>(mean); oq = dpp_f<0x128>(q);   // row_ror:8 = the other half of the 16-lane row
                     }
                     const float delta = om - mean;
-                    q = q + oq + delta * delta * (0.5f * IN_WAVE);
+                    q = __builtin_fmaf(delta * delta, 0.5f * IN_WAVE, q + oq);
                     const float shift = -0.5f * delta;   // old mean - merged mean
 #pragma unroll
                     for (int i = 0; i < 4; ++i) d2[i] = d2[i] + shift;
                 }
-                const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / GS) + eps);
+                const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(q, 1.0f / GS, eps));
                 bf16x8 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const f32x2 a2 = f32x2{gam[2 * i], gam[2 * i + 1]} * rstd;
-                    const f32x2 y2 = d2[i] * a2 + f32x2{bet[2 * i], bet[2 * i + 1]};
+                    const f32x2 y2 = __builtin_elementwise_fma(d2[i], a2, f32x2{bet[2 * i], bet[2 * i + 1]});
                     f32x2 e2 = y2 * -1.4426950408889634f;
                     e2 = f32x2{__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])} + 1.0f;
                     const f32x2 o2 = y2 * f32x2{__builtin_amdgcn_rcpf(e2[0]), __builtin_amdgcn_rcpf(e2[1])};
@@ -276,8 +279,93 @@ struct Epilogue {
                                                     float eps, const bool (&live)[R], int wave, int rr, int cg) {
         static_assert(GS <= WTN, "gn_multi: the group must lie inside the wave");
         outv_t o[R];
+        if constexpr (BF && GS >= 8) {
+            // gn_compute's bf16 arithmetic, row for row the same operations in the same order, written operation by operation
+            // ACROSS the rows: the scheduler keeps source order, so the R dependency chains (DPP sums, v_exp, v_rcp) interleave
+#pragma clang fp contract(off)
+            constexpr bool DPP_SPLIT = WTN == 128 && GS == 128;
+            constexpr int IN_WAVE = DPP_SPLIT ? 64 : GS;
+            constexpr int LANES = IN_WAVE / 8;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 d2[R][4], q2[R];
+            float mean[R], q[R], rstd[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) gn_compute<GS>(v[r], gam, bet, o[r], eps, nullptr, wave, rr, cg);
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d2[r][i] = f32x2{v[r][2 * i], v[r][2 * i + 1]};
+                const f32x2 t2 = (d2[r][0] + d2[r][1]) + (d2[r][2] + d2[r][3]);
+                mean[r] = t2[0] + t2[1];
+            }
+            auto sum_rows = [&](float (&x)[R]) {
+                if constexpr (LANES >= 2) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) x[r] += dpp_f<0xB1>(x[r]);
+                }
+                if constexpr (LANES >= 4) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) x[r] += dpp_f<0x4E>(x[r]);
+                }
+                if constexpr (LANES >= 8) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) x[r] += dpp_f<0x141>(x[r]);
+                }
+            };
+            sum_rows(mean);
+#pragma unroll
+            for (int r = 0; r < R; ++r) mean[r] *= 1.0f / IN_WAVE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r) d2[r][i] = d2[r][i] - mean[r];
+#pragma unroll
+            for (int r = 0; r < R; ++r) q2[r] = d2[r][0] * d2[r][0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r) q2[r] = __builtin_elementwise_fma(d2[r][i], d2[r][i], q2[r]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) q[r] = q2[r][0] + q2[r][1];
+            sum_rows(q);
+            if constexpr (DPP_SPLIT) {
+                float om[R], oq[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { om[r] = dpp_f<0x128>(mean[r]); oq[r] = dpp_f<0x128>(q[r]); }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float delta = om[r] - mean[r];
+                    q[r] = __builtin_fmaf(delta * delta, 0.5f * IN_WAVE, q[r] + oq[r]);
+                    const float shift = -0.5f * delta;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d2[r][i] = d2[r][i] + shift;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) rstd[r] = __builtin_amdgcn_rsqf(__builtin_fmaf(q[r], 1.0f / GS, eps));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x2 y2[R], e2[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const f32x2 a2 = f32x2{gam[2 * i], gam[2 * i + 1]} * rstd[r];
+                    y2[r] = __builtin_elementwise_fma(d2[r][i], a2, f32x2{bet[2 * i], bet[2 * i + 1]});
+                    e2[r] = y2[r] * -1.4426950408889634f;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) e2[r] = f32x2{__builtin_amdgcn_exp2f(e2[r][0]), __builtin_amdgcn_exp2f(e2[r][1])} + 1.0f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const f32x2 o2 = y2[r] * f32x2{__builtin_amdgcn_rcpf(e2[r][0]), __builtin_amdgcn_rcpf(e2[r][1])};
+                    o[r][2 * i] = (bf16_t)o2[0];
+                    o[r][2 * i + 1] = (bf16_t)o2[1];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) gn_compute<GS>(v[r], gam, bet, o[r], eps, nullptr, wave, rr, cg);
+        }
+        // keep the arithmetic in front of the lane-dependent stores (the compiler would sink each row's into its branch)
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("" : "+v"(o[r]));
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (live[r]) *reinterpret_cast<outv_t*>(dst[r]) = o[r];
@@ -1188,7 +1276,6 @@ __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams 
                    "{v136}"(v_src0[0]), "{v137}"(v_src1[0]), "{v138}"(v_src0[1]), "{v139}"(v_src1[1]), "{v140}"(v_src0[2]), "{v141}"(v_src1[2]),
                    "{v144}"(v_pf[0]), "{v145}"(v_pf[1]), "{v146}"(v_pf[2])
                  : ADCDIFF_W4_CLOBBERS);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last prefetch loads (their data is never used)
     __syncthreads();
     Epi::template run<true, EPI_U>(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
 }

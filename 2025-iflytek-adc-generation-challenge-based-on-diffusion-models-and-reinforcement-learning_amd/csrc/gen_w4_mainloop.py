@@ -245,6 +245,8 @@ def generate():
     # ---- last two tiles: nothing left to issue
     tile(False)
     tile(False, last=True)
+    # the last prefetch load may still be in flight: its result register is the compiler's again after this statement
+    e("s_waitcnt vmcnt(0)")
     # the compiler does not know that MFMAs are still writing the accumulators it reads next
     e("s_nop 15")
     e("s_nop 15")
