@@ -83,7 +83,7 @@ class AdamWArgs(C.Structure):
 
 OPT_CHUNK = 4096
 OPT_NOALLOC_MAX_CHUNKS = 65536
-KIND_GEMM_F32, KIND_GEMM_BF16, KIND_GROUPNORM, KIND_UPDATE, KIND_GEMM_BF16_T256, KIND_OTHER = 0, 1, 2, 3, 4, 5
+KIND_GEMM_F32, KIND_GEMM_BF16, KIND_GROUPNORM, KIND_UPDATE, KIND_GEMM_BF16_T256, KIND_OTHER, KIND_GEMM_BF16_W256 = 0, 1, 2, 3, 4, 5, 6
 
 # name -> (restype, argtypes): every symbol include/adcdiff.h declares
 SIGNATURES = {

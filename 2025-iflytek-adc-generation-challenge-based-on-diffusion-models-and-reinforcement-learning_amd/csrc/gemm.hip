@@ -1458,17 +1458,17 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     // only where the GroupNorm groups stay inside a 32-column wave tile: every kernel then sums a group in the same
     // order, so a row's result does not depend on the batch size it is computed in (bit for bit)
     for (int g = 0; g < a.n_gn; ++g) small = small && a.gn[g].group_size <= 32;
-    const int kind = a.dtype == ADCDIFF_F32 ? ADCDIFF_KIND_GEMM_F32 : big ? ADCDIFF_KIND_GEMM_BF16_T256 : ADCDIFF_KIND_GEMM_BF16;
+    // big: the 4-wave kernel with the assembly main loop unless the launch splits K, has a single K tile, or a hint / the
+    // measurement aid ADCDIFF_GEMM_W4=0 asks for one of the 8-wave kernels
+    static const bool w4_default = [] { const char* e = getenv("ADCDIFF_GEMM_W4"); return e ? atoi(e) != 0 : true; }();
+    const bool w4_hint = a.tile_hint == 2564 || a.tile_hint == 2565 || a.tile_hint == 2566 || a.tile_hint == 2568;
+    const bool w4 = big && p.ksplit == 1 && p.nt_total >= 2 &&
+                    (w4_hint || (w4_default && a.tile_hint != 2560 && a.tile_hint != 2561 && a.tile_hint != 256));
+    const int kind = a.dtype == ADCDIFF_F32 ? ADCDIFF_KIND_GEMM_F32 : w4 ? ADCDIFF_KIND_GEMM_BF16_W256 : big ? ADCDIFF_KIND_GEMM_BF16_T256 : ADCDIFF_KIND_GEMM_BF16;
     TimingScope ts(kind, a.M, a.N, ktot, 2.0 * a.M * a.N * ktot,
                    esz * ((double)a.M * ktot + (double)a.N * ktot) + (double)a.M * a.N * (nout + (a.residual ? esz : 0.0)), stream);
     if (big) {
-        // the 4-wave kernel with the assembly main loop unless the launch splits K, has a single K tile, or a hint / the
-        // measurement aid ADCDIFF_GEMM_W4=0 asks for one of the 8-wave kernels
-        static const bool w4_default = [] { const char* e = getenv("ADCDIFF_GEMM_W4"); return e ? atoi(e) != 0 : true; }();
-        const bool w4_ok = p.ksplit == 1 && p.nt_total >= 2;
-        const bool w4_hint = a.tile_hint == 2564 || a.tile_hint == 2565 || a.tile_hint == 2566 || a.tile_hint == 2568;
-        const bool w4 = w4_ok && (w4_hint || (w4_default && a.tile_hint != 2560 && a.tile_hint != 2561 && a.tile_hint != 256));
-        // measurement aids: 2565 / 2566 / 2568 = epilogue load batches of 1 / 2 / 8 steps
+        // measurement aids: 2565 / 2566 / 2568 = epilogue batches of 1 / 2 / 8 rows per lane
         if (w4) return a.tile_hint == 2565 ? launch256w<1>(p, stream) : a.tile_hint == 2566 ? launch256w<2>(p, stream)
                      : a.tile_hint == 2568 ? launch256w<8>(p, stream) : launch256w<4>(p, stream);
         return launch256(p, pipelined, stream);

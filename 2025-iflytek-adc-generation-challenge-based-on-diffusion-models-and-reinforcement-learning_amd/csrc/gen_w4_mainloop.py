@@ -183,6 +183,11 @@ def tile(issue, last=False):
 
 
 def generate():
+    global PF
+    PF = 4
+    for f in ABLATE:
+        if f.startswith("pf") and f[2:].isdigit():
+            PF = int(f[2:])
     # ---- set-up
     e("s_mov_b32 s73, m0")
     e("s_mov_b32 s60, s40")

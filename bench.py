@@ -119,11 +119,17 @@ def timed_window(fn):
 def summarize_records(records, dtype, units, algo_flop_per_unit, workload):
     """Roofline objects from per-launch records (timed_window): `units` = samples x denoising steps (or training samples)
     inside the window.  The record times add up to the window's device time."""
-    gemm_kinds = (_lib.KIND_GEMM_BF16, _lib.KIND_GEMM_BF16_T256, _lib.KIND_GEMM_F32)
+    gemm_kinds = (_lib.KIND_GEMM_BF16, _lib.KIND_GEMM_BF16_T256, _lib.KIND_GEMM_BF16_W256, _lib.KIND_GEMM_F32)
     gemm = [r for r in records if r["kind"] in gemm_kinds]
+    w4 = [r for r in gemm if r["kind"] == _lib.KIND_GEMM_BF16_W256]
     big = [r for r in gemm if r["kind"] == _lib.KIND_GEMM_BF16_T256]
     small_name = "gemm_nt_kernel<%s>" % ("bf16" if dtype == "bf16" else "float")
-    dom, dom_name, dom_key = (big, "gemm256_bf16_kernel", "gemm256_kernel<bf16>") if big else (gemm, small_name, small_name)
+    if w4:
+        dom, dom_name, dom_key = w4, "gemm256w_bf16_kernel", "gemm256w_kernel<bf16>"
+    elif big:
+        dom, dom_name, dom_key = big, "gemm256_bf16_kernel", "gemm256_kernel<bf16>"
+    else:
+        dom, dom_name, dom_key = gemm, small_name, small_name
     peak = PEAK_TFLOPS[dtype]
     window_ms = sum(r["ms"] for r in records)
     dom_ms = sum(r["ms"] for r in dom)

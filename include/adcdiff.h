@@ -111,8 +111,10 @@ typedef struct adcdiff_gemm_args {
     int n_gn;                  /* 0..2 fused SiLU(GroupNorm(v)) outputs */
     adcdiff_gn_out gn[2];
     float gn_eps;
-    int tile_hint;             /* 0 = choose; 128 / 256 = force that tile kernel where the shape allows; 1 / 3 = force the 128-row kernel
-                                  with one LDS stage / the three-stage ring (A/B measurements, tests) */
+    int tile_hint;             /* 0 = choose; 128 / 256 = force that tile kernel where the shape allows (256 = the eight-wave 256 x 256
+                                  kernel; 2560 / 2561 = its phased / ring main loop; 2564 = the four-wave 256 x 256 kernel with the
+                                  assembly main loop, which 0 picks for large bf16 layers); 1 / 3 = force the 128-row kernel with one
+                                  LDS stage / the three-stage ring (A/B measurements, tests) */
     int split_k;               /* 0 / 1 = off.  S > 1: the K dimension (one segment, a multiple of S * 64 bf16 / S * 32 f32) is cut
                                   into S equal slices computed by separate workgroups; slice s writes its partial product to
                                   out_f32 + s * split_stride and the caller sums the S partials in a fixed order.  For
@@ -336,7 +338,8 @@ int adcdiff_clip_adamw_step_noalloc(const adcdiff_opt_tensor* tensors, int n_ten
  * to it.  All launches of a window must go to ONE stream.  Not thread safe; not for use under graph capture. */
 enum { ADCDIFF_KIND_GEMM_F32 = 0, ADCDIFF_KIND_GEMM_BF16 = 1, ADCDIFF_KIND_GROUPNORM = 2, ADCDIFF_KIND_UPDATE = 3,
        ADCDIFF_KIND_GEMM_BF16_T256 = 4 /* bf16 GEMM that ran on the 256 x 256-tile kernel */,
-       ADCDIFF_KIND_OTHER = 5 /* every other kernel launch of the library (casts, transposes, backward element-wise kernels, optimizer) */ };
+       ADCDIFF_KIND_OTHER = 5 /* every other kernel launch of the library (casts, transposes, backward element-wise kernels, optimizer) */,
+       ADCDIFF_KIND_GEMM_BF16_W256 = 6 /* bf16 GEMM that ran on the four-wave 256 x 256-tile kernel (assembly main loop) */ };
 typedef struct adcdiff_timing_record {
     int kind;
     int M, N, K;        /* GEMM: rows, outputs, total K; others: rows, columns, 0 */

@@ -458,6 +458,11 @@ __global__ __launch_bounds__(256, 1) void w4asm_kernel(const Params p) {
     else if constexpr (V == 5) asm volatile(W4LAB_mfmaonly : W4_OUTS : W4_INS : W4_CLOBBERS);
     else if constexpr (V == 6) asm volatile(W4LAB_dmafirsthalf : W4_OUTS : W4_INS : W4_CLOBBERS);
     else if constexpr (V == 7) asm volatile(W4LAB_nopf : W4_OUTS : W4_INS : W4_CLOBBERS);
+    else if constexpr (V == 8) asm volatile(W4LAB_pf2 : W4_OUTS : W4_INS : W4_CLOBBERS);
+    else if constexpr (V == 9) asm volatile(W4LAB_pf3 : W4_OUTS : W4_INS : W4_CLOBBERS);
+    else if constexpr (V == 10) asm volatile(W4LAB_pf6 : W4_OUTS : W4_INS : W4_CLOBBERS);
+    else if constexpr (V == 11) asm volatile(W4LAB_pf8 : W4_OUTS : W4_INS : W4_CLOBBERS);
+    else if constexpr (V == 12) asm volatile(W4LAB_pf12 : W4_OUTS : W4_INS : W4_CLOBBERS);
     const long long t2 = __builtin_amdgcn_s_memtime();
 
     bf16_t* C = p.C;
@@ -551,6 +556,12 @@ int main(int argc, char** argv) {
         {"ring8 (8 waves 128x64)", launch<4, 0>, 8, true},
         {"w4asm (4 waves 128x128, asm loop)", launch_w4asm<0, 0>, 4, true},
         {"w4asm no prefetch", launch_w4asm<7, 0>, 4, true},
+        {"w4asm prefetch distance 2", launch_w4asm<8, 0>, 4, true},
+        {"w4asm prefetch distance 3", launch_w4asm<9, 0>, 4, true},
+        {"w4asm prefetch distance 6", launch_w4asm<10, 0>, 4, true},
+        {"w4asm prefetch distance 8", launch_w4asm<11, 0>, 4, true},
+        {"w4asm prefetch distance 12", launch_w4asm<12, 0>, 4, true},
+        {"w4asm (again)", launch_w4asm<0, 0>, 4, true},
         {"w4asm no DMA", launch_w4asm<1, 0>, 4, false},
         {"w4asm no fragment reads", launch_w4asm<2, 0>, 4, false},
         {"w4asm no barrier", launch_w4asm<3, 0>, 4, false},

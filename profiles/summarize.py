@@ -19,6 +19,8 @@ def one(pattern):
 def short(name):
     if "gemm_nt_kernel" in name:
         return "gemm_nt_kernel<bf16>" if "DF16b" in name or "bf16" in name else "gemm_nt_kernel<float>"
+    if "gemm256w" in name:
+        return "gemm256w_kernel<bf16>"
     if "gemm256" in name:
         return "gemm256_kernel<bf16>"
     for key in ("gn_silu_vec_kernel", "gn_silu_generic_kernel", "ddpm_step_kernel", "ddim_step_kernel", "philox_normal_kernel",
