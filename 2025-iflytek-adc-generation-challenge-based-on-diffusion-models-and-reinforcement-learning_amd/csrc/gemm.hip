@@ -1250,12 +1250,15 @@ __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams 
     const int v_boff1 = (int)lds0 + 32768 + (wn * WTN + frow) * 128 + (((4 + fchunk) ^ fx) << 4);
     // LDS-DMA source offsets: piece j of the wave = its rows 8 j .. 8 j + 7, lane -> row 8 j + (lane >> 3), chunk position
     // lane & 7, which holds chunk (lane & 7) ^ ((row >> 1) & 7) = (lane & 7) ^ ((4 j + (lane >> 4)) & 7): two offsets, by the parity of j
-    // Prefetch offsets: the ntn workgroups of a tile row split its 256 A rows (share rows each, inside ONE loader wave's half);
-    // the lanes of that wave point at the share's lines (64 / share consecutive K tiles deep), every other wave at one line.
-    const int share = p.ntn >= 2 ? 256 / p.ntn : 128, prow0 = p.ntn >= 2 ? nidx * share : half * 128;
+    // Prefetch offsets: the ntn workgroups of a tile row split its 256 A rows.  Four or more workgroups: a share of 256 / ntn
+    // <= 64 rows lies in ONE loader wave's half; its lanes point at the share's lines, 64 / share consecutive K tiles deep,
+    // every other wave at a single line (which costs nothing).  Two workgroups: each A loader takes 64 rows of its own half
+    // (workgroup 0 the first 64, workgroup 1 the second).  One workgroup: the first 64 rows of each half (half the lines).
+    const int share = p.ntn >= 4 ? 256 / p.ntn : 64;
+    const int prow0 = p.ntn >= 4 ? nidx * share : half * 128 + (p.ntn == 2 ? nidx * 64 : 0);
     const bool pf_wave = loads_a && (prow0 >> 7) == half;
-    const int pf_row = (prow0 & 127) + (share >= 64 ? lane : lane % share);   // a share of 128 rows is covered by half (64 lanes)
-    const int pf_k = share >= 64 ? 0 : (lane / share) * 128;
+    const int pf_row = (prow0 & 127) + lane % share;
+    const int pf_k = (lane / share) * 128;
     int v_src0[3], v_src1[3], v_pf[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -1458,12 +1461,13 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     // only where the GroupNorm groups stay inside a 32-column wave tile: every kernel then sums a group in the same
     // order, so a row's result does not depend on the batch size it is computed in (bit for bit)
     for (int g = 0; g < a.n_gn; ++g) small = small && a.gn[g].group_size <= 32;
-    // big: the 4-wave kernel with the assembly main loop unless the launch splits K, has a single K tile, or a hint / the
-    // measurement aid ADCDIFF_GEMM_W4=0 asks for one of the 8-wave kernels
+    // big: the 4-wave kernel with the assembly main loop unless the launch splits K, has a single K tile, is one tile wide (the
+    // 8-wave kernel's epilogue is the faster one there and the main loop is short), or a hint / the measurement aid
+    // ADCDIFF_GEMM_W4=0 asks for one of the 8-wave kernels
     static const bool w4_default = [] { const char* e = getenv("ADCDIFF_GEMM_W4"); return e ? atoi(e) != 0 : true; }();
     const bool w4_hint = a.tile_hint == 2564 || a.tile_hint == 2565 || a.tile_hint == 2566 || a.tile_hint == 2568;
     const bool w4 = big && p.ksplit == 1 && p.nt_total >= 2 &&
-                    (w4_hint || (w4_default && a.tile_hint != 2560 && a.tile_hint != 2561 && a.tile_hint != 256));
+                    (w4_hint || (w4_default && a.N >= 512 && a.tile_hint != 2560 && a.tile_hint != 2561 && a.tile_hint != 256));
     const int kind = a.dtype == ADCDIFF_F32 ? ADCDIFF_KIND_GEMM_F32 : w4 ? ADCDIFF_KIND_GEMM_BF16_W256 : big ? ADCDIFF_KIND_GEMM_BF16_T256 : ADCDIFF_KIND_GEMM_BF16;
     TimingScope ts(kind, a.M, a.N, ktot, 2.0 * a.M * a.N * ktot,
                    esz * ((double)a.M * ktot + (double)a.N * ktot) + (double)a.M * a.N * (nout + (a.residual ? esz : 0.0)), stream);
