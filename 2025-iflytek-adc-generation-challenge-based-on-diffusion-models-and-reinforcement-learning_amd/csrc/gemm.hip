@@ -703,6 +703,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 3 : 2) void gemm_nt_kernel(const
     const int nwg = gridDim.x;
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int m0 = (bid / p.ntn) * BM, n0 = (bid % p.ntn) * BN;
+    if (m0 >= p.m_valid) return;   // a row tile of padding only (a batch of 32 in 128 padded rows): nothing to store
     Epi::stage_params(p, n0, tid, prm);
 
     // staging: lane l of piece q fills LDS row 8q + (l >> 3), chunk position l & 7, which holds the logical
