@@ -186,3 +186,14 @@ def test_custom_operators_are_registered_with_schemas_and_fake_rules():
         assert eps.shape == (256, 512)
         loop = torch.ops.adcdiff.ddpm_sample_loop(1, x, None, torch.empty(1000, 4), 999, 0, None, 5, 0, ws)
         assert loop.shape == x.shape
+
+
+def test_generated_assembly_main_loop_is_what_the_generator_writes(tmp_path):
+    """csrc/w4_mainloop.inc (the hand-allocated main loop of the four-wave GEMM) is committed; it must equal the output of
+    csrc/gen_w4_mainloop.py, so that the register map documented in the generator is the one the library was built from."""
+    import subprocess
+    import sys
+    csrc = os.path.join(os.path.dirname(os.path.abspath(adcdiff._lib.__file__)), "csrc")
+    out = tmp_path / "w4.inc"
+    subprocess.run([sys.executable, os.path.join(csrc, "gen_w4_mainloop.py"), str(out)], check=True)
+    assert out.read_text() == open(os.path.join(csrc, "w4_mainloop.inc")).read()
