@@ -1461,7 +1461,12 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     bool small = (long)(a.M / 128) * (a.N / (wide ? 128 : 64)) * p.ksplit < 256 && a.tile_hint != 128 && a.tile_hint != 1 && a.tile_hint != 3;
     // only where the GroupNorm groups stay inside a 32-column wave tile: every kernel then sums a group in the same
     // order, so a row's result does not depend on the batch size it is computed in (bit for bit)
+    const bool few = small;
     for (int g = 0; g < a.n_gn; ++g) small = small && a.gn[g].group_size <= 32;
+    // the same launches with groups of 64 channels: 64 rows x 128 columns (a 32 x 64 wave tile holds a whole group), half
+    // the MFMA work of a 128-row tile whose upper rows are padding
+    bool mid = few && !small && wide;
+    for (int g = 0; g < a.n_gn; ++g) mid = mid && a.gn[g].group_size <= 64;
     // big: the 4-wave kernel with the assembly main loop unless the launch splits K, has a single K tile, is one tile wide (the
     // 8-wave kernel's epilogue is the faster one there and the main loop is short), or a hint / the measurement aid
     // ADCDIFF_GEMM_W4=0 asks for one of the 8-wave kernels
@@ -1479,15 +1484,17 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         return launch256(p, pipelined, stream);
     }
     // few workgroups: nothing else on the CU hides a tile's load latency, so take the three-stage ring
-    const int bn = small ? 64 : wide ? 128 : 64, bm = small ? 64 : 128;
+    const int bn = small ? 64 : wide ? 128 : 64, bm = small || mid ? 64 : 128;
     const long blocks = (long)(a.M / bm) * (a.N / bn) * p.ksplit;
     static const long ring_max = [] { const char* e = getenv("ADCDIFF_GEMM_RING_MAX"); return e ? atol(e) : 512L; }();   // measurement aid
     const bool ring = a.tile_hint == 3 || (a.tile_hint != 1 && blocks <= ring_max);
     if (a.dtype == ADCDIFF_BF16) {
         if (small) return launch_any<bf16_t, 64, 64>(p, ring, stream);
+        if (mid) return launch_any<bf16_t, 64, 128>(p, ring, stream);
         return wide ? launch_any<bf16_t, 128, 128>(p, ring, stream) : launch_any<bf16_t, 128, 64>(p, ring, stream);
     }
     if (small) return launch_any<float, 64, 64>(p, ring, stream);
+    if (mid) return launch_any<float, 64, 128>(p, ring, stream);
     return wide ? launch_any<float, 128, 128>(p, ring, stream) : launch_any<float, 128, 64>(p, ring, stream);
 }
 
