@@ -95,7 +95,9 @@ class MoleculeGenerator:
         """(primary, fallback) strings for one summary row.  primary = _add_functional_groups(base) over the base chosen
         by the mean thresholds (molecule_generator.py:1084-1126); fallback = the drug-like table entry selected by
         int(|sum| * 15) % 15 (:1158-1161).  The reference returns primary when RDKit validates it and fallback otherwise
-        (:1062-1066); that check stays with the caller."""
+        (:1062-1066); that check stays with the caller.  The reference's functional-group tests are three separate `if`s
+        (:1110-1126); each taken branch returns, so the `elif` chain below selects the same string.  No execution of the
+        reference pins this heuristic (it imports rdkit, which is not installed): parity unpinned."""
         mean, total, f3, f5, f8 = (float(v) for v in summary_row)
         if mean > 0.5:
             base = "c1ccccc1"
