@@ -1363,6 +1363,10 @@ template <typename T, int BM, int BN>
 static int launch_any(const GemmParams& p, bool ring, hipStream_t stream) {
     // three stages: deeper rings (six stages of 64 x 64, four of 128 x 128) measured 3-5 % slower -- past a prefetch distance
     // of two tiles the per-tile barrier and LDS-DMA issue are the critical path, not the load latency
+    // more workgroups than CUs (fp32 batch 4096: 512 tiles of 128 x 128): two stages of 32 KiB let two workgroups share a CU,
+    // and one computes while the other waits at its barrier: +8 % samples/s over three stages with one workgroup per CU
+    static const bool two_ok = [] { const char* e = getenv("ADCDIFF_GEMM_RING2"); return e ? atoi(e) != 0 : true; }();   // measurement aid
+    if (ring && two_ok && BM == 128 && BN == 128 && (long)(p.M / BM) * (p.N / BN) * p.ksplit > 256) return launch<T, BM, BN, 2>(p, stream);
     return ring ? launch<T, BM, BN, 3>(p, stream) : launch<T, BM, BN, 1>(p, stream);
 }
 
