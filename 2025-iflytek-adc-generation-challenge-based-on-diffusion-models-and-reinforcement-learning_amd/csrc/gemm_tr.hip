@@ -18,6 +18,8 @@
 // 128 x 128 tile, 4 waves (2 x 2, 64 x 64 per wave), K step 64, three-stage ring with one barrier per step (the NT
 // kernel's ring).  Output: float32, written straight from the accumulator layout; grid.y slices the contraction, every
 // slice writing its own partial output (summed by the caller in slice order).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace adcdiff {
@@ -55,9 +57,11 @@ __device__ __forceinline__ bf16x8 tr_fragment(const char* tile, int k0, int c0, 
     return __builtin_bit_cast(bf16x8, both);
 }
 
-template <bool TA>
-__global__ __launch_bounds__(256, 1) void gemm_tr_kernel(const TrParams p) {
-    constexpr int STAGE_BYTES = 32768, A_BYTES = 16384, NSTAGE = 3, AHEAD = NSTAGE - 1, P = 8;
+// NSTAGE = 3: one workgroup per CU with two tiles in flight; NSTAGE = 2 (64 KiB): two workgroups share a CU and one computes
+// while the other waits at its barrier -- for launches with more workgroups than CUs.
+template <bool TA, int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void gemm_tr_kernel(const TrParams p) {
+    constexpr int STAGE_BYTES = 32768, A_BYTES = 16384, AHEAD = NSTAGE - 1, P = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,6 +160,16 @@ __global__ __launch_bounds__(256, 1) void gemm_tr_kernel(const TrParams p) {
             }
 }
 
+template <bool TA, int NSTAGE>
+static int launch_tr(const TrParams& p, dim3 grid, hipStream_t stream) {
+    constexpr int smem = NSTAGE * 32768;
+    // once per process, thread-safe (initialisation of a function-local static)
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tr_kernel<TA, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm_tr: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((gemm_tr_kernel<TA, NSTAGE>), grid, dim3(256), smem, stream, p);
+    return ADCDIFF_OK;
+}
+
 // C[M, N] (+ slices) = A * B over K.  ta: A is [K, M] row-major (lda >= M), else [M, K] row-major (lda >= K); B is [K, N]
 // row-major.  slices > 1: slice s takes K / slices contraction rows and writes C + s * c_slice.
 int gemm_tr(bool ta, const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, int slices, long c_slice,
@@ -175,17 +189,14 @@ int gemm_tr(bool ta, const void* A, long lda, const void* B, long ldb, float* C,
     p.a_slice = ta ? (long)kslice * lda : (long)kslice;
     p.b_slice = (long)kslice * ldb;
     p.c_slice = slices > 1 ? c_slice : 0;
-    constexpr int smem = 3 * 32768;
-    static const hipError_t attr_err = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tr_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    }();
-    if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm_tr: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     const dim3 grid((unsigned)((M / 128) * p.ntn), (unsigned)slices);
     TimingScope ts(ADCDIFF_KIND_GEMM_BF16, M, N, K, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N * slices, stream);
-    if (ta) hipLaunchKernelGGL(gemm_tr_kernel<true>, grid, dim3(256), smem, stream, p);
-    else hipLaunchKernelGGL(gemm_tr_kernel<false>, grid, dim3(256), smem, stream, p);
+    static const bool two_ok = [] { const char* e = getenv("ADCDIFF_GEMM_RING2"); return e ? atoi(e) != 0 : true; }();   // measurement aid
+    const bool two = two_ok && (long)grid.x * grid.y > 256;
+    int rc;
+    if (two) rc = ta ? launch_tr<true, 2>(p, grid, stream) : launch_tr<false, 2>(p, grid, stream);
+    else rc = ta ? launch_tr<true, 3>(p, grid, stream) : launch_tr<false, 3>(p, grid, stream);
+    if (rc != ADCDIFF_OK) return rc;
     return check_launch("gemm_tr");
 }
 
