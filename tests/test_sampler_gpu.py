@@ -140,9 +140,10 @@ def test_batch_4096_rows_are_independent_and_shardable(golden_a):
 
 
 def test_batch_65536_bf16_rows_are_independent_of_the_tiling(golden_a):
-    """Config 3 (bf16 operands, batch 65536 -- the 256 x 256-tile kernel with its phased main loop): rows of the big batch
-    equal the same rows sampled in a batch of 256 (128-row kernel, three-stage ring) and of 77 (64-row tiles), bit for bit,
-    with and without a condition; so the probes that pin the small batches pin the benchmark's batch."""
+    """Config 3 (bf16 operands, batch 65536 -- the four-wave 256 x 256-tile kernel with the assembly main loop for the layers
+    at least 512 wide, the eight-wave 256 x 256 kernel for the 256-wide ones): rows of the big batch equal the same rows sampled
+    in a batch of 256 (128-row kernel, three-stage ring) and of 77 (64-row tiles), bit for bit, with and without a condition
+    (a third K segment for the loader); so the probes that pin the small batches pin the benchmark's batch."""
     m, _ = build((512, 256, 512), "bf16")
     steps = dict(t_start=999, t_stop=995)
     B = 65536
