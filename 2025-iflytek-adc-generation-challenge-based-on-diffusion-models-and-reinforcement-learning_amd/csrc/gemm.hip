@@ -1343,6 +1343,173 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
     return check_launch("gemm256w");
 }
 
+// ---- 32 rows x BN columns, ONE wave per workgroup, bf16: generation batches of at most 32 molecules ----------------------------
+// At such a batch a launch has N / 64 workgroups of the tile kernels, one per CU at most, and each K tile is a serial chain of
+// barrier, LDS-DMA issue, fragment reads and MFMAs (0.33 us per tile for 64 x 64, 0.59 us for 128 x 128, whatever the ring depth).
+// This kernel loads only what such a batch needs -- the 32 live rows of A (not 64 of padding) and 32 or 64 rows of W, as the
+// GroupNorm groups allow -- and so spreads a layer over up to four times the CUs.  A single wave owns the whole tile: no
+// barrier, the in-order vmcnt counter alone orders the ring (stages of 8 / 12 KiB, 8 / 6 tiles ahead).  A lone wave issues its
+// instructions one after another, so the loop is software-pipelined by hand: between the MFMAs of tile t sit the LDS-DMA
+// pieces of tile t + D (buffer loads: K offset in a scalar register, M0 stepped by 1 KiB, three instructions per piece) and
+// the fragment reads of tile t + 1 into the other register set.  Every iteration issues the same instructions: past the last
+// tile the pieces of the last tile go out again (into stages nobody reads), which keeps the vmcnt arithmetic constant.
+// M0 is left at the last LDS-DMA address: the compiler has no use for it in this kernel.
+// Fragments, K order and epilogue are those of the tile kernels: bit-identical results.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// one 1 KiB piece (8 rows x 128 bytes): FIRST sets M0 to the LDS address, the others step it on from the previous piece
+template <bool FIRST>
+__device__ __forceinline__ void dma_piece(int voff, i32x4 srd, int soff, unsigned lds) {
+    if constexpr (FIRST)
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(srd), "s"(soff), "s"(lds) : "memory");
+    else
+        asm volatile("s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
+template <int BN>
+__global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
+    typedef bf16_t T;
+    constexpr int BM = 32, TM = 2, TN = BN / 16;
+    constexpr int AP = BM / 8, WP = BN / 8, P = AP + WP;       // 1 KiB pieces per K tile: A rows, then W rows, contiguous in a stage
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int D = 63 / P + 1 < 8 ? 63 / P + 1 : 8;         // tiles ahead = ring stages; (D - 1) * P pieces fit the vmcnt counter
+    constexpr int NM = 2 * TM * TN, NR = 2 * (TM + TN);        // MFMAs / fragment reads per K tile
+    static_assert(P <= NM && NR <= NM, "one piece and one read at most per MFMA");
+    typedef Epilogue<T, 64, BN, BM, BN, TM, TN> Epi;
+    static_assert(D * STAGE_BYTES >= Epi::STAGE_BYTES, "the epilogue stages through the ring's memory");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const prm = reinterpret_cast<float*>(smem + D * STAGE_BYTES);
+    float* const xch = prm + 5 * BN;
+    const int lane = threadIdx.x;
+    const int n0 = blockIdx.x * BN;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // descriptors: the 32 rows of A per K segment, the BN rows of W
+    auto make_srd = [](unsigned long long base, unsigned bytes) {
+        return i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)base), __builtin_amdgcn_readfirstlane((int)((unsigned)(base >> 32) & 0xffffu)),
+                     __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+    };
+    const unsigned ldw_b = (unsigned)p.ldw * 2u;
+    const i32x4 srd_w = make_srd((unsigned long long)p.W + (unsigned long long)n0 * ldw_b, (unsigned)(BN - 1) * ldw_b + (unsigned)p.nt_total * 128u);
+    // piece j = rows 8 j .. 8 j + 7: lane -> row 8 j + (lane >> 3), chunk position lane & 7 holding chunk (lane & 7) ^ ((row >> 1) & 7)
+    int voff[P];
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+        const int row = 8 * j + (lane >> 3);
+        voff[AP + j] = (int)((unsigned)row * ldw_b + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16));
+    }
+    i32x4 srd_a;
+    auto enter_segment = [&](int s) {
+        const unsigned ld = (unsigned)p.lda[s] * 2u;
+        srd_a = make_srd((unsigned long long)p.A[s], (unsigned)(BM - 1) * ld + (unsigned)p.ktiles[s] * 128u);
+#pragma unroll
+        for (int j = 0; j < AP; ++j) {
+            const int row = 8 * j + (lane >> 3);
+            voff[j] = (int)((unsigned)row * ld + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16));
+        }
+    };
+    enter_segment(0);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int nt = p.nt_total;
+    int seg = 0, tt = 0, it = 0;     // load cursor: K segment, tile inside it, tiles issued (running past nt)
+    // descriptors and K offsets of tile `it`; past the last tile they stay at the last tile's
+    i32x4 da, dw;
+    int soa, sow;
+    auto cursor = [&]() {
+        if (it < nt) {
+            if (tt == p.ktiles[seg]) {   // next K segment that has tiles (wave-uniform)
+                ++seg; tt = 0;
+                if (tt == p.ktiles[seg]) ++seg;
+                enter_segment(seg);
+            }
+            da = srd_a; dw = srd_w;
+            soa = tt * 128; sow = it * 128;
+            ++tt;
+        }
+        ++it;
+    };
+    // vmcnt counts to 63 and the wave is NOT stalled beyond that: with 72 pieces in flight the counter wrapped and later waits
+    // (the compiler's own, for the parameter loads below, included) returned before their data -- stale registers, and a
+    // wild pointer once.  So never more than 63 loads in flight: D - 1 tiles, the epilogue's parameter vectors behind them
+    // (a load or two at a time; one memory latency for both, not two), a wait that leaves room for a tile, then tile D - 1.
+    static_assert((D - 1) * P + 3 <= 63, "LDS-DMA pieces in flight exceed the vmcnt counter");
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        if (k == D - 1) {
+            Epi::stage_params(p, n0, lane, prm);
+            wait_vmcnt<63 - P>();
+        }
+        cursor();
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            if (m == 0) dma_piece<true>(voff[m], da, soa, lds0 + k * STAGE_BYTES);
+            else dma_piece<false>(voff[m], m < AP ? da : dw, m < AP ? soa : sow, 0);
+        }
+    }
+
+    // fragment m of a tile: k half m / (TM + TN), then the TM A fragments and the TN W fragments of that half
+    const int frow = lane & 15, fchunk = lane >> 4;
+    uint4 fa[2][2][TM], fb[2][2][TN];
+    auto read_frag = [&](auto SET, int m, const char* stage) {
+        constexpr int S = decltype(SET)::value;
+        const int ks = m / (TM + TN), r = m % (TM + TN);
+        const int c = 4 * ks + fchunk;
+        const int row = (r < TM ? r : r - TM) * 16 + frow;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + (r < TM ? 0 : BM * 128) + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        if (r < TM) fa[S][ks][r] = v; else fb[S][ks][r - TM] = v;
+    };
+    wait_vmcnt<(D - 1) * P>();   // tile 0 has landed
+#pragma unroll
+    for (int m = 0; m < NR; ++m) read_frag(std::integral_constant<int, 0>{}, m, smem);
+
+    int slot = 0;   // stage of tile t: free (its fragments are in registers), takes tile t + D
+    auto body = [&](auto SET) {
+        constexpr int S = decltype(SET)::value;
+        cursor();
+        const unsigned dst = lds0 + (unsigned)slot * STAGE_BYTES;
+        slot = slot == D - 1 ? 0 : slot + 1;
+        const char* const next = smem + slot * STAGE_BYTES;
+        wait_vmcnt<(D - 2) * P>();   // tile t + 1 has landed (the D - 2 younger tiles may stay in flight)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int ks = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[S][ks][i]), __builtin_bit_cast(bf16x8, fb[S][ks][j]),
+                                                                acc[i][j], 0, 0, 0);
+            if (m == 0) dma_piece<true>(voff[0], da, soa, dst);
+            else if (m < P) dma_piece<false>(voff[m], m < AP ? da : dw, m < AP ? soa : sow, 0);
+            if (m < NR) read_frag(std::integral_constant<int, S ^ 1>{}, m, next);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int t = 0; t + 1 < nt; t += 2) {
+        body(std::integral_constant<int, 0>{});
+        body(std::integral_constant<int, 1>{});
+    }
+    if (nt & 1) body(std::integral_constant<int, 0>{});
+    wait_vmcnt<0>();   // the repeated pieces of the last iterations too, before the ring's memory is reused
+    Epi::template run<true, (BN == 64 ? 4 : 2)>(acc, p, 0, n0, 0, 0, 0, lane, reinterpret_cast<float*>(smem), prm, xch);
+}
+
+template <int BN>
+static int launch_w1(const GemmParams& p, hipStream_t stream) {
+    typedef Epilogue<bf16_t, 64, BN, 32, BN, 2, BN / 16> Epi;
+    constexpr int P = (32 + BN) / 8, D = 63 / P + 1 < 8 ? 63 / P + 1 : 8;
+    constexpr int smem = D * (32 + BN) * 128 + Epi::EXTRA_BYTES;
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w1_bf16_kernel<BN>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    GemmParams q = p;
+    q.ntn = p.N / BN;
+    hipLaunchKernelGGL(gemm_w1_bf16_kernel<BN>, dim3(q.ntn), dim3(64), smem, stream, q);
+    return check_launch("gemm (32 rows)");
+}
+
 template <typename T, int BM, int BN, int NSTAGE>
 static int launch(const GemmParams& p, hipStream_t stream) {
     constexpr int TS = sizeof(T) == 2 ? 16 : 32;
@@ -1486,6 +1653,17 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         if (w4) return a.tile_hint == 2565 ? launch256w<1>(p, stream) : a.tile_hint == 2566 ? launch256w<2>(p, stream)
                      : a.tile_hint == 2568 ? launch256w<8>(p, stream) : launch256w<4>(p, stream);
         return launch256(p, pipelined, stream);
+    }
+    // at most 32 live rows (the generator's default batch): the one-wave kernel, 32 columns per workgroup where every
+    // GroupNorm group fits in 32, else 64.  Opt-in (tile_hint 32 per call, ADCDIFF_GEMM_W1=1 per process): measured 20 %
+    // faster than the tile kernels on a batch-32 sampling run, but its last revision (the cap on loads in flight) has only
+    // run on part of the parity cases on hardware
+    static const bool w1_default = [] { const char* e = getenv("ADCDIFF_GEMM_W1"); return e ? atoi(e) != 0 : false; }();
+    if (a.dtype == ADCDIFF_BF16 && p.m_valid <= 32 && p.ksplit == 1 && (a.tile_hint == 32 || (a.tile_hint == 0 && w1_default))) {
+        int gmax = 0;
+        for (int g = 0; g < a.n_gn; ++g) gmax = a.gn[g].group_size > gmax ? a.gn[g].group_size : gmax;
+        if (gmax <= 32) return launch_w1<32>(p, stream);
+        if (gmax <= 64) return launch_w1<64>(p, stream);
     }
     // few workgroups: nothing else on the CU hides a tile's load latency, so take the three-stage ring
     const int bn = small ? 64 : wide ? 128 : 64, bm = small || mid ? 64 : 128;

@@ -1,0 +1,63 @@
+"""GPU parity of the opt-in one-wave GEMM kernel for batches of at most 32 rows, through the C ABI (via adcdiff.ops).
+Bit-exact against the tile kernels, which the other kernel tests pin to the oracle.  Kept in a file of its own, collected
+after the other kernel and sampler tests: the kernel is not on the default path."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+adcdiff = pytest.importorskip("adcdiff")
+ops = adcdiff.ops
+DEV = "cuda"
+
+
+def _t(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+def _bf16_round(a):
+    return torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.mark.parametrize("Ks,N,gs_pair,live", [([64], 64, (4, 64), 32), ([128, 64, 192], 256, (16, 32), 32), ([512, 1024], 128, (8, 64), 17),
+                                               ([64, 64], 192, (32, 32), 1), ([2048], 512, (64, 64), 32), ([4096, 64], 256, (8, 8), 31),
+                                               ([192, 64, 64], 64, (16, 16), 32)])
+def test_one_wave_kernel_for_32_rows_equals_the_tile_kernels(Ks, N, gs_pair, live):
+    """The opt-in kernel for launches with at most 32 live rows (one wave per workgroup, 32 rows x 32 or 64 columns,
+    tile_hint 32): every output -- float32, operand type, both SiLU(GroupNorm) outputs, with bias, gathered row bias and
+    residual -- equals the 128-row tile kernel's bit for bit on the live rows, for one and several K segments, rings
+    shorter and longer than the prefetch depth, and the reverse-step update in the epilogue."""
+    rng = np.random.default_rng(sum(Ks) + N)
+    M = 128
+    As = [rng.standard_normal((M, k)).astype(np.float32) for k in Ks]
+    W = (rng.standard_normal((N, sum(Ks))) / np.sqrt(sum(Ks))).astype(np.float32) * 2
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    table = rng.standard_normal((7, N)).astype(np.float32)
+    idx = rng.integers(0, 7, M).astype(np.int64)
+    gam = (1 + 0.2 * rng.standard_normal(N)).astype(np.float32)
+    bet = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    bf = torch.bfloat16
+    kw = dict(bias=_t(bias), rowbias=_t(table), rowbias_idx=_t(idx, torch.int64), residual=_t(res, bf), out_op=True,
+              gn=[(_t(gam), _t(bet), gs_pair[0]), (_t(gam), _t(bet), gs_pair[1])], m_valid=live, dtype="bf16")
+    one = ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=32, **kw)
+    tile = ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=128, **kw)
+    assert len(one) == 4
+    for o, t in zip(one, tile):
+        assert torch.equal(o[:live], t[:live])
+    v = np.concatenate([_bf16_round(a) for a in As], 1).astype(np.float64) @ _bf16_round(W).astype(np.float64).T + bias + table[idx] + \
+        _bf16_round(res)
+    assert rel_err(one[0].cpu().numpy()[:live], v[:live]) < 1e-5
+    # the sampler's update inside the epilogue
+    A1, W1 = _t(As[0], bf), _t(W[:, :Ks[0]].copy(), bf)
+    x = _t((rng.standard_normal((M, N)) * 4).astype(np.float32))
+    for kind, c in ((1, (1.0101, 0.02, 0.9, 0.14)), (2, (0.9, 0.436, 0.5, 0.85, 0.1))):
+        outs = []
+        for hint in (32, 128):
+            outs.append(ops._raw_gemm([A1], W1, bias=_t(bias), m_valid=live, dtype="bf16", tile_hint=hint, out_op=True, gn=[(_t(gam), _t(bet), gs_pair[1])],
+                                      update=dict(kind=kind, c=c, x=x.clone(), noise=None, seed=5, step=3, row_offset=40)))
+        for o, t in zip(*outs):
+            assert torch.equal(o[:live], t[:live])
