@@ -136,7 +136,6 @@ def test_gemm_256_tile_kernel_matches_128_tile_kernel(Ks, hint):
     assert np.abs(big[3].float().cpu().numpy()[:M - 9] - ref[:M - 9]).max() < 2.0 ** -8 * np.abs(ref).max() + 1e-5
 
 
-
 def test_gemm_asymmetric_layout():
     """A = I against an asymmetric W catches a transposed or permuted accumulator map."""
     M = N = K = 128

@@ -1,3 +1,6 @@
+"""Manual probe (GPU): the one-wave GEMM kernel (tile_hint 32) against the 128-row tile kernel for every combination of the
+epilogue options on one small shape (N = 64, K = 64, 32 live rows); prints the largest difference per output (0.0 = bit-identical).
+It was how the stale parameter vectors from a wrapped vmcnt counter were narrowed down to bias + GroupNorm."""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 import adcdiff
