@@ -1350,29 +1350,36 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
 // GroupNorm groups allow -- and so spreads a layer over up to four times the CUs.  A single wave owns the whole tile: no
 // barrier, the in-order vmcnt counter alone orders the ring (stages of 8 / 12 KiB, 8 / 6 tiles ahead).  A lone wave issues its
 // instructions one after another, so the loop is software-pipelined by hand: between the MFMAs of tile t sit the LDS-DMA
-// pieces of tile t + D (buffer loads: K offset in a scalar register, M0 stepped by 1 KiB, three instructions per piece) and
+// pieces of tile t + D (buffer loads: K offset in a scalar register, M0 written once per four pieces) and
 // the fragment reads of tile t + 1 into the other register set.  Every iteration issues the same instructions: past the last
 // tile the pieces of the last tile go out again (into stages nobody reads), which keeps the vmcnt arithmetic constant.
 // M0 is left at the last LDS-DMA address: the compiler has no use for it in this kernel.
 // Fragments, K order and epilogue are those of the tile kernels: bit-identical results.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// one 1 KiB piece (8 rows x 128 bytes): FIRST sets M0 to the LDS address, the others step it on from the previous piece
-template <bool FIRST>
-__device__ __forceinline__ void dma_piece(int voff, i32x4 srd, int soff, unsigned lds) {
-    if constexpr (FIRST)
+// Piece m of a tile (1 KiB: 8 rows x 128 bytes) into LDS at the tile's stage + 1024 m.  M0 is written once per four pieces
+// (absolutely for m = 0, stepped by 4 KiB for m = 4, 8); the other three reach their slots through the instruction's offset
+// field, which shifts the global address as well: their lane offsets `voff` are computed 1024 (m & 3) lower to make up for it.
+__device__ __forceinline__ void dma_piece(int m, int voff, i32x4 srd, int soff, unsigned lds) {
+    if (m == 0)
         asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(srd), "s"(soff), "s"(lds) : "memory");
+    else if ((m & 3) == 0)
+        asm volatile("s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(srd), "s"(soff) : "memory");
+    else if ((m & 3) == 1)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:1024 lds" : : "v"(voff), "s"(srd), "s"(soff) : "memory");
+    else if ((m & 3) == 2)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:2048 lds" : : "v"(voff), "s"(srd), "s"(soff) : "memory");
     else
-        asm volatile("s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(srd), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:3072 lds" : : "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 
-template <int BN>
+template <int BN, int DMAX = 8>
 __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     typedef bf16_t T;
     constexpr int BM = 32, TM = 2, TN = BN / 16;
     constexpr int AP = BM / 8, WP = BN / 8, P = AP + WP;       // 1 KiB pieces per K tile: A rows, then W rows, contiguous in a stage
     constexpr int STAGE_BYTES = (BM + BN) * 128;
-    constexpr int D = 63 / P + 1 < 8 ? 63 / P + 1 : 8;         // tiles ahead = ring stages; (D - 1) * P pieces fit the vmcnt counter
+    constexpr int D = 63 / P + 1 < DMAX ? 63 / P + 1 : DMAX;   // tiles ahead = ring stages; (D - 1) * P pieces fit the vmcnt counter
     constexpr int NM = 2 * TM * TN, NR = 2 * (TM + TN);        // MFMAs / fragment reads per K tile
     static_assert(P <= NM && NR <= NM, "one piece and one read at most per MFMA");
     typedef Epilogue<T, 64, BN, BM, BN, TM, TN> Epi;
@@ -1391,12 +1398,13 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     };
     const unsigned ldw_b = (unsigned)p.ldw * 2u;
     const i32x4 srd_w = make_srd((unsigned long long)p.W + (unsigned long long)n0 * ldw_b, (unsigned)(BN - 1) * ldw_b + (unsigned)p.nt_total * 128u);
-    // piece j = rows 8 j .. 8 j + 7: lane -> row 8 j + (lane >> 3), chunk position lane & 7 holding chunk (lane & 7) ^ ((row >> 1) & 7)
+    // piece j = rows 8 j .. 8 j + 7: lane -> row 8 j + (lane >> 3), chunk position lane & 7 holding chunk (lane & 7) ^ ((row >> 1) & 7);
+    // less 1024 (j & 3) for the instruction offset (rows are at least 128 bytes apart, so the offset stays non-negative)
     int voff[P];
 #pragma unroll
     for (int j = 0; j < WP; ++j) {
         const int row = 8 * j + (lane >> 3);
-        voff[AP + j] = (int)((unsigned)row * ldw_b + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16));
+        voff[AP + j] = (int)((unsigned)row * ldw_b + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16)) - 1024 * ((AP + j) & 3);
     }
     i32x4 srd_a;
     auto enter_segment = [&](int s) {
@@ -1405,7 +1413,7 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < AP; ++j) {
             const int row = 8 * j + (lane >> 3);
-            voff[j] = (int)((unsigned)row * ld + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16));
+            voff[j] = (int)((unsigned)row * ld + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16)) - 1024 * (j & 3);
         }
     };
     enter_segment(0);
@@ -1448,8 +1456,7 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
         cursor();
 #pragma unroll
         for (int m = 0; m < P; ++m) {
-            if (m == 0) dma_piece<true>(voff[m], da, soa, lds0 + k * STAGE_BYTES);
-            else dma_piece<false>(voff[m], m < AP ? da : dw, m < AP ? soa : sow, 0);
+            dma_piece(m, voff[m], m < AP ? da : dw, m < AP ? soa : sow, lds0 + k * STAGE_BYTES);
         }
     }
 
@@ -1481,8 +1488,7 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
             const int ks = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[S][ks][i]), __builtin_bit_cast(bf16x8, fb[S][ks][j]),
                                                                 acc[i][j], 0, 0, 0);
-            if (m == 0) dma_piece<true>(voff[0], da, soa, dst);
-            else if (m < P) dma_piece<false>(voff[m], m < AP ? da : dw, m < AP ? soa : sow, 0);
+            if (m < P) dma_piece(m, voff[m], m < AP ? da : dw, m < AP ? soa : sow, dst);
             if (m < NR) read_frag(std::integral_constant<int, S ^ 1>{}, m, next);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1496,17 +1502,17 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     Epi::template run<true, (BN == 64 ? 4 : 2)>(acc, p, 0, n0, 0, 0, 0, lane, reinterpret_cast<float*>(smem), prm, xch);
 }
 
-template <int BN>
+template <int BN, int DMAX = 8>
 static int launch_w1(const GemmParams& p, hipStream_t stream) {
     typedef Epilogue<bf16_t, 64, BN, 32, BN, 2, BN / 16> Epi;
-    constexpr int P = (32 + BN) / 8, D = 63 / P + 1 < 8 ? 63 / P + 1 : 8;
+    constexpr int P = (32 + BN) / 8, D = 63 / P + 1 < DMAX ? 63 / P + 1 : DMAX;
     constexpr int smem = D * (32 + BN) * 128 + Epi::EXTRA_BYTES;
-    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w1_bf16_kernel<BN>),
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w1_bf16_kernel<BN, DMAX>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmParams q = p;
     q.ntn = p.N / BN;
-    hipLaunchKernelGGL(gemm_w1_bf16_kernel<BN>, dim3(q.ntn), dim3(64), smem, stream, q);
+    hipLaunchKernelGGL((gemm_w1_bf16_kernel<BN, DMAX>), dim3(q.ntn), dim3(64), smem, stream, q);
     return check_launch("gemm (32 rows)");
 }
 
@@ -1658,9 +1664,11 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     // GroupNorm group fits in 32, else 64 (a batch-32 sampling run takes 24 % less time than on the tile kernels); tile_hint 32
     // asks for it, any other hint (or the measurement aid ADCDIFF_GEMM_W1=0) for the tile kernels
     static const bool w1_default = [] { const char* e = getenv("ADCDIFF_GEMM_W1"); return e ? atoi(e) != 0 : true; }();
-    if (a.dtype == ADCDIFF_BF16 && p.m_valid <= 32 && p.ksplit == 1 && (a.tile_hint == 32 || (a.tile_hint == 0 && w1_default))) {
+    if (a.dtype == ADCDIFF_BF16 && p.m_valid <= 32 && p.ksplit == 1 && (a.tile_hint == 32 || a.tile_hint == 324 || (a.tile_hint == 0 && w1_default))) {
         int gmax = 0;
         for (int g = 0; g < a.n_gn; ++g) gmax = a.gn[g].group_size > gmax ? a.gn[g].group_size : gmax;
+        // measurement aid: 324 = a ring of four stages (is a tile's time set by the tiles in flight or by the instruction issue?)
+        if (a.tile_hint == 324) return gmax <= 32 ? launch_w1<32, 4>(p, stream) : launch_w1<64, 4>(p, stream);
         if (gmax <= 32) return launch_w1<32>(p, stream);
         if (gmax <= 64) return launch_w1<64>(p, stream);
     }

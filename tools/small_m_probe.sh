@@ -7,5 +7,5 @@ for cfg in "2048 256 64" "2048 1024 64" "2048 2048 64" "2048 4096 64" "2048 256 
   d=gpurun_out/prof_smallm/$1_$2_$3
   timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 tools/small_m_probe.py $1 $2 $3 > $d.log 2>&1 || { echo "failed $cfg"; tail -3 $d.log; exit 1; }
   f=$(find $d -name "*kernel_stats.csv" | head -1)
-  echo "N=$1 K=$2 gs=$3: $(grep "gemm_" $f | head -1 | awk -F, '{gsub(/"/,""); printf "%s calls %s avg %.1f us", substr($1,1,60), $2, $4/1000}')"
+  echo "N=$1 K=$2 gs=$3: $(python3 tools/kernel_avg.py $f gemm_)"
 done
