@@ -1354,6 +1354,9 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
 // the fragment reads of tile t + 1 into the other register set.  Every iteration issues the same instructions: past the last
 // tile the pieces of the last tile go out again (into stages nobody reads), which keeps the vmcnt arithmetic constant.
 // M0 is left at the last LDS-DMA address: the compiler has no use for it in this kernel.
+// What bounds a tile now is the LDS-DMA path itself, about 40 cycles per 1 KiB piece and CU (the four-wave kernel pays the same
+// 42): a four-stage ring, a third fewer scalar instructions, a padded row pitch of W and a split into a loader and a compute
+// wave all left the tile time where it was.
 // Fragments, K order and epilogue are those of the tile kernels: bit-identical results.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -1373,13 +1376,13 @@ __device__ __forceinline__ void dma_piece(int m, int voff, i32x4 srd, int soff, 
         asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:3072 lds" : : "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 
-template <int BN, int DMAX = 8>
+template <int BN>
 __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     typedef bf16_t T;
     constexpr int BM = 32, TM = 2, TN = BN / 16;
     constexpr int AP = BM / 8, WP = BN / 8, P = AP + WP;       // 1 KiB pieces per K tile: A rows, then W rows, contiguous in a stage
     constexpr int STAGE_BYTES = (BM + BN) * 128;
-    constexpr int D = 63 / P + 1 < DMAX ? 63 / P + 1 : DMAX;   // tiles ahead = ring stages; (D - 1) * P pieces fit the vmcnt counter
+    constexpr int D = 63 / P + 1 < 8 ? 63 / P + 1 : 8;         // tiles ahead = ring stages; (D - 1) * P pieces fit the vmcnt counter
     constexpr int NM = 2 * TM * TN, NR = 2 * (TM + TN);        // MFMAs / fragment reads per K tile
     static_assert(P <= NM && NR <= NM, "one piece and one read at most per MFMA");
     typedef Epilogue<T, 64, BN, BM, BN, TM, TN> Epi;
@@ -1502,17 +1505,17 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     Epi::template run<true, (BN == 64 ? 4 : 2)>(acc, p, 0, n0, 0, 0, 0, lane, reinterpret_cast<float*>(smem), prm, xch);
 }
 
-template <int BN, int DMAX = 8>
+template <int BN>
 static int launch_w1(const GemmParams& p, hipStream_t stream) {
     typedef Epilogue<bf16_t, 64, BN, 32, BN, 2, BN / 16> Epi;
-    constexpr int P = (32 + BN) / 8, D = 63 / P + 1 < DMAX ? 63 / P + 1 : DMAX;
+    constexpr int P = (32 + BN) / 8, D = 63 / P + 1 < 8 ? 63 / P + 1 : 8;
     constexpr int smem = D * (32 + BN) * 128 + Epi::EXTRA_BYTES;
-    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w1_bf16_kernel<BN, DMAX>),
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w1_bf16_kernel<BN>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmParams q = p;
     q.ntn = p.N / BN;
-    hipLaunchKernelGGL((gemm_w1_bf16_kernel<BN, DMAX>), dim3(q.ntn), dim3(64), smem, stream, q);
+    hipLaunchKernelGGL(gemm_w1_bf16_kernel<BN>, dim3(q.ntn), dim3(64), smem, stream, q);
     return check_launch("gemm (32 rows)");
 }
 
@@ -1664,11 +1667,9 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     // GroupNorm group fits in 32, else 64 (a batch-32 sampling run takes 24 % less time than on the tile kernels); tile_hint 32
     // asks for it, any other hint (or the measurement aid ADCDIFF_GEMM_W1=0) for the tile kernels
     static const bool w1_default = [] { const char* e = getenv("ADCDIFF_GEMM_W1"); return e ? atoi(e) != 0 : true; }();
-    if (a.dtype == ADCDIFF_BF16 && p.m_valid <= 32 && p.ksplit == 1 && (a.tile_hint == 32 || a.tile_hint == 324 || (a.tile_hint == 0 && w1_default))) {
+    if (a.dtype == ADCDIFF_BF16 && p.m_valid <= 32 && p.ksplit == 1 && (a.tile_hint == 32 || (a.tile_hint == 0 && w1_default))) {
         int gmax = 0;
         for (int g = 0; g < a.n_gn; ++g) gmax = a.gn[g].group_size > gmax ? a.gn[g].group_size : gmax;
-        // measurement aid: 324 = a ring of four stages (is a tile's time set by the tiles in flight or by the instruction issue?)
-        if (a.tile_hint == 324) return gmax <= 32 ? launch_w1<32, 4>(p, stream) : launch_w1<64, 4>(p, stream);
         if (gmax <= 32) return launch_w1<32>(p, stream);
         if (gmax <= 64) return launch_w1<64>(p, stream);
     }

@@ -21,10 +21,10 @@ def _kernel_text():
     return s[a:s.index("static int launch_w1", a)]
 
 
-def _consts(bn, dmax=8):
+def _consts(bn):
     """P, D and the four wait constants, evaluated from the expressions in the source."""
     k = _kernel_text()
-    env = {"BM": 32, "BN": bn, "DMAX": dmax}
+    env = {"BM": 32, "BN": bn}
     env["AP"], env["WP"] = env["BM"] // 8, bn // 8
     env["P"] = env["AP"] + env["WP"]
     m = re.search(r"constexpr int D = ([^;]+);", k)
@@ -54,11 +54,10 @@ class InOrderCounter:
         return bool(idx) and idx[-1] < self.landed
 
 
-@pytest.mark.parametrize("dmax", [8, 4])
 @pytest.mark.parametrize("bn", [32, 64])
 @pytest.mark.parametrize("nt", list(range(1, 20)) + [31, 32, 64, 65])
-def test_ring_schedule_of_the_one_wave_kernel(bn, nt, dmax):
-    P, D, (w_room, w_first, w_iter, w_end) = _consts(bn, dmax)
+def test_ring_schedule_of_the_one_wave_kernel(bn, nt):
+    P, D, (w_room, w_first, w_iter, w_end) = _consts(bn)
     assert (D - 1) * P + 3 <= 63
     c = InOrderCounter()
     stage_tile = {}           # stage -> tile whose pieces were issued into it last

@@ -26,6 +26,7 @@ def _bf16_round(a):
                                                ([64, 64], 192, (32, 32), 1), ([2048], 512, (64, 64), 32), ([4096, 64], 256, (8, 8), 31),
                                                ([192, 64, 64], 64, (16, 16), 32)])
 def test_one_wave_kernel_for_32_rows_equals_the_tile_kernels(Ks, N, gs_pair, live):
+    hint = 32
     """Launches with at most 32 live rows default to a kernel with one wave per workgroup (32 rows x 32 or 64 columns;
     tile_hint 32 asks for it): every output -- float32, operand type, both SiLU(GroupNorm) outputs, with bias, gathered row bias and
     residual -- equals the 128-row tile kernel's bit for bit on the live rows, for one and several K segments, rings
@@ -43,7 +44,7 @@ def test_one_wave_kernel_for_32_rows_equals_the_tile_kernels(Ks, N, gs_pair, liv
     bf = torch.bfloat16
     kw = dict(bias=_t(bias), rowbias=_t(table), rowbias_idx=_t(idx, torch.int64), residual=_t(res, bf), out_op=True,
               gn=[(_t(gam), _t(bet), gs_pair[0]), (_t(gam), _t(bet), gs_pair[1])], m_valid=live, dtype="bf16")
-    one = ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=32, **kw)
+    one = ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=hint, **kw)
     dflt = ops.gemm([_t(a, bf) for a in As], _t(W, bf), **kw)
     tile = ops.gemm([_t(a, bf) for a in As], _t(W, bf), tile_hint=128, **kw)
     assert len(one) == 4
@@ -57,8 +58,8 @@ def test_one_wave_kernel_for_32_rows_equals_the_tile_kernels(Ks, N, gs_pair, liv
     x = _t((rng.standard_normal((M, N)) * 4).astype(np.float32))
     for kind, c in ((1, (1.0101, 0.02, 0.9, 0.14)), (2, (0.9, 0.436, 0.5, 0.85, 0.1))):
         outs = []
-        for hint in (32, 128):
-            outs.append(ops._raw_gemm([A1], W1, bias=_t(bias), m_valid=live, dtype="bf16", tile_hint=hint, out_op=True, gn=[(_t(gam), _t(bet), gs_pair[1])],
+        for h in (hint, 128):
+            outs.append(ops._raw_gemm([A1], W1, bias=_t(bias), m_valid=live, dtype="bf16", tile_hint=h, out_op=True, gn=[(_t(gam), _t(bet), gs_pair[1])],
                                       update=dict(kind=kind, c=c, x=x.clone(), noise=None, seed=5, step=3, row_offset=40)))
         for o, t in zip(*outs):
             assert torch.equal(o[:live], t[:live])
