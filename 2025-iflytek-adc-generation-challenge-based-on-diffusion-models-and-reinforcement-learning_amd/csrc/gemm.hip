@@ -1343,7 +1343,7 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
     return check_launch("gemm256w");
 }
 
-// ---- 32 rows x BN columns, ONE wave per workgroup, bf16: generation batches of at most 32 molecules ----------------------------
+// ---- 32 rows x BN columns (32 / 64 / 128 by the widest GroupNorm group), ONE wave per workgroup, bf16: batches of at most 32 ----------------------------
 // At such a batch a launch has N / 64 workgroups of the tile kernels, one per CU at most, and each K tile is a serial chain of
 // barrier, LDS-DMA issue, fragment reads and MFMAs (0.33 us per tile for 64 x 64, 0.59 us for 128 x 128, whatever the ring depth).
 // This kernel loads only what such a batch needs -- the 32 live rows of A (not 64 of padding) and 32 or 64 rows of W, as the
@@ -1502,7 +1502,7 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     }
     if (nt & 1) body(std::integral_constant<int, 0>{});
     wait_vmcnt<0>();   // the repeated pieces of the last iterations too, before the ring's memory is reused
-    Epi::template run<true, (BN == 64 ? 4 : 2)>(acc, p, 0, n0, 0, 0, 0, lane, reinterpret_cast<float*>(smem), prm, xch);
+    Epi::template run<true, (BN >= 64 ? 4 : 2)>(acc, p, 0, n0, 0, 0, 0, lane, reinterpret_cast<float*>(smem), prm, xch);
 }
 
 template <int BN>
@@ -1664,7 +1664,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         return launch256(p, pipelined, stream);
     }
     // at most 32 live rows (the generator's default batch): the one-wave kernel, 32 columns per workgroup where every
-    // GroupNorm group fits in 32, else 64 (a batch-32 sampling run takes 24 % less time than on the tile kernels); tile_hint 32
+    // GroupNorm group fits in 32, else 64 or 128 (a batch-32 sampling run takes 24 % less time than on the tile kernels); tile_hint 32
     // asks for it, any other hint (or the measurement aid ADCDIFF_GEMM_W1=0) for the tile kernels
     static const bool w1_default = [] { const char* e = getenv("ADCDIFF_GEMM_W1"); return e ? atoi(e) != 0 : true; }();
     if (a.dtype == ADCDIFF_BF16 && p.m_valid <= 32 && p.ksplit == 1 && (a.tile_hint == 32 || (a.tile_hint == 0 && w1_default))) {
@@ -1672,6 +1672,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         for (int g = 0; g < a.n_gn; ++g) gmax = a.gn[g].group_size > gmax ? a.gn[g].group_size : gmax;
         if (gmax <= 32) return launch_w1<32>(p, stream);
         if (gmax <= 64) return launch_w1<64>(p, stream);
+        if (a.N % 128 == 0) return launch_w1<128>(p, stream);   // groups of 128 channels: the two halves of 64 meet inside a 16-lane row
     }
     // few workgroups: nothing else on the CU hides a tile's load latency, so take the three-stage ring
     const int bn = small ? 64 : wide ? 128 : 64, bm = small || mid ? 64 : 128;

@@ -54,7 +54,7 @@ class InOrderCounter:
         return bool(idx) and idx[-1] < self.landed
 
 
-@pytest.mark.parametrize("bn", [32, 64])
+@pytest.mark.parametrize("bn", [32, 64, 128])
 @pytest.mark.parametrize("nt", list(range(1, 20)) + [31, 32, 64, 65])
 def test_ring_schedule_of_the_one_wave_kernel(bn, nt):
     P, D, (w_room, w_first, w_iter, w_end) = _consts(bn)

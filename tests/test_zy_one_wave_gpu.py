@@ -24,7 +24,8 @@ def _bf16_round(a):
 
 @pytest.mark.parametrize("Ks,N,gs_pair,live", [([64], 64, (4, 64), 32), ([128, 64, 192], 256, (16, 32), 32), ([512, 1024], 128, (8, 64), 17),
                                                ([64, 64], 192, (32, 32), 1), ([2048], 512, (64, 64), 32), ([4096, 64], 256, (8, 8), 31),
-                                               ([192, 64, 64], 64, (16, 16), 32)])
+                                               ([192, 64, 64], 64, (16, 16), 32), ([512, 1024], 256, (128, 8), 32), ([64], 128, (128, 128), 17),
+                                               ([2048, 1024], 384, (64, 128), 32)])
 def test_one_wave_kernel_for_32_rows_equals_the_tile_kernels(Ks, N, gs_pair, live):
     hint = 32
     """Launches with at most 32 live rows default to a kernel with one wave per workgroup (32 rows x 32 or 64 columns;
