@@ -1343,11 +1343,11 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
     return check_launch("gemm256w");
 }
 
-// ---- 32 rows x BN columns (32 / 64 / 128 by the widest GroupNorm group), ONE wave per workgroup, bf16: batches of at most 32 ----------------------------
+// ---- BM (32 / 64) rows x BN (32 / 64 / 128 by the widest GroupNorm group) columns, ONE wave per workgroup, bf16: batches <= 64 ----------------------------
 // At such a batch a launch has N / 64 workgroups of the tile kernels, one per CU at most, and each K tile is a serial chain of
 // barrier, LDS-DMA issue, fragment reads and MFMAs (0.33 us per tile for 64 x 64, 0.59 us for 128 x 128, whatever the ring depth).
-// This kernel loads only what such a batch needs -- the 32 live rows of A (not 64 of padding) and 32 or 64 rows of W, as the
-// GroupNorm groups allow -- and so spreads a layer over up to four times the CUs.  A single wave owns the whole tile: no
+// This kernel loads only what such a batch needs -- 32 or 64 rows of A (not 64 of padding for a batch of 32) and 32 to 128 rows
+// of W, as the GroupNorm groups allow -- and so spreads a layer over up to four times the CUs.  A single wave owns the whole tile: no
 // barrier, the in-order vmcnt counter alone orders the ring (stages of 8 / 12 KiB, 8 / 6 tiles ahead).  A lone wave issues its
 // instructions one after another, so the loop is software-pipelined by hand: between the MFMAs of tile t sit the LDS-DMA
 // pieces of tile t + D (buffer loads: K offset in a scalar register, M0 written once per four pieces) and
@@ -1376,10 +1376,10 @@ __device__ __forceinline__ void dma_piece(int m, int voff, i32x4 srd, int soff, 
         asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:3072 lds" : : "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 
-template <int BN>
+template <int BM, int BN>
 __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     typedef bf16_t T;
-    constexpr int BM = 32, TM = 2, TN = BN / 16;
+    constexpr int TM = BM / 16, TN = BN / 16;
     constexpr int AP = BM / 8, WP = BN / 8, P = AP + WP;       // 1 KiB pieces per K tile: A rows, then W rows, contiguous in a stage
     constexpr int STAGE_BYTES = (BM + BN) * 128;
     constexpr int D = 63 / P + 1 < 8 ? 63 / P + 1 : 8;         // tiles ahead = ring stages; (D - 1) * P pieces fit the vmcnt counter
@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     const int n0 = blockIdx.x * BN;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-    // descriptors: the 32 rows of A per K segment, the BN rows of W
+    // descriptors: the BM rows of A per K segment, the BN rows of W
     auto make_srd = [](unsigned long long base, unsigned bytes) {
         return i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)base), __builtin_amdgcn_readfirstlane((int)((unsigned)(base >> 32) & 0xffffu)),
                      __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
@@ -1505,18 +1505,18 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     Epi::template run<true, (BN >= 64 ? 4 : 2)>(acc, p, 0, n0, 0, 0, 0, lane, reinterpret_cast<float*>(smem), prm, xch);
 }
 
-template <int BN>
+template <int BM, int BN>
 static int launch_w1(const GemmParams& p, hipStream_t stream) {
-    typedef Epilogue<bf16_t, 64, BN, 32, BN, 2, BN / 16> Epi;
-    constexpr int P = (32 + BN) / 8, D = 63 / P + 1 < 8 ? 63 / P + 1 : 8;
-    constexpr int smem = D * (32 + BN) * 128 + Epi::EXTRA_BYTES;
-    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w1_bf16_kernel<BN>),
+    typedef Epilogue<bf16_t, 64, BN, BM, BN, BM / 16, BN / 16> Epi;
+    constexpr int P = (BM + BN) / 8, D = 63 / P + 1 < 8 ? 63 / P + 1 : 8;
+    constexpr int smem = D * (BM + BN) * 128 + Epi::EXTRA_BYTES;
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w1_bf16_kernel<BM, BN>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmParams q = p;
     q.ntn = p.N / BN;
-    hipLaunchKernelGGL(gemm_w1_bf16_kernel<BN>, dim3(q.ntn), dim3(64), smem, stream, q);
-    return check_launch("gemm (32 rows)");
+    hipLaunchKernelGGL((gemm_w1_bf16_kernel<BM, BN>), dim3(q.ntn), dim3(64), smem, stream, q);
+    return check_launch("gemm (one wave per tile)");
 }
 
 template <typename T, int BM, int BN, int NSTAGE>
@@ -1663,16 +1663,18 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
                      : a.tile_hint == 2568 ? launch256w<8>(p, stream) : launch256w<4>(p, stream);
         return launch256(p, pipelined, stream);
     }
-    // at most 32 live rows (the generator's default batch): the one-wave kernel, 32 columns per workgroup where every
-    // GroupNorm group fits in 32, else 64 or 128 (a batch-32 sampling run takes 24 % less time than on the tile kernels); tile_hint 32
+    // at most 64 live rows (the generator's default batch is 32): the one-wave kernel, 32 or 64 rows and 32 columns per workgroup
+    // where every GroupNorm group fits in 32, else 64 or 128 (a batch-32 sampling run takes 24 % less time than on the tile kernels); tile_hint 32
     // asks for it, any other hint (or the measurement aid ADCDIFF_GEMM_W1=0) for the tile kernels
     static const bool w1_default = [] { const char* e = getenv("ADCDIFF_GEMM_W1"); return e ? atoi(e) != 0 : true; }();
-    if (a.dtype == ADCDIFF_BF16 && p.m_valid <= 32 && p.ksplit == 1 && (a.tile_hint == 32 || (a.tile_hint == 0 && w1_default))) {
+    if (a.dtype == ADCDIFF_BF16 && p.m_valid <= 64 && p.ksplit == 1 && (a.tile_hint == 32 || (a.tile_hint == 0 && w1_default))) {
         int gmax = 0;
         for (int g = 0; g < a.n_gn; ++g) gmax = a.gn[g].group_size > gmax ? a.gn[g].group_size : gmax;
-        if (gmax <= 32) return launch_w1<32>(p, stream);
-        if (gmax <= 64) return launch_w1<64>(p, stream);
-        if (a.N % 128 == 0) return launch_w1<128>(p, stream);   // groups of 128 channels: the two halves of 64 meet inside a 16-lane row
+        const bool r32 = p.m_valid <= 32;
+        if (gmax <= 32) return r32 ? launch_w1<32, 32>(p, stream) : launch_w1<64, 32>(p, stream);
+        if (gmax <= 64) return r32 ? launch_w1<32, 64>(p, stream) : launch_w1<64, 64>(p, stream);
+        // groups of 128 channels: the two halves of 64 meet inside a 16-lane row
+        if (a.N % 128 == 0) return r32 ? launch_w1<32, 128>(p, stream) : launch_w1<64, 128>(p, stream);
     }
     // few workgroups: nothing else on the CU hides a tile's load latency, so take the three-stage ring
     const int bn = small ? 64 : wide ? 128 : 64, bm = small || mid ? 64 : 128;

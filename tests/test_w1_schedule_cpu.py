@@ -1,7 +1,7 @@
 """CPU model of the one-wave GEMM kernel's LDS ring (gemm_w1_bf16_kernel in csrc/gemm.hip): the wait constants are read from
 the source and replayed against an in-order load counter, the way the hardware's vmcnt behaves.
 
-What the model checks, for every K-tile count and both tile widths:
+What the model checks, for every K-tile count and every tile shape:
 * never more than 63 loads in flight (the 6-bit counter wraps beyond that and later waits return early);
 * every fragment read of a tile comes after a wait that guarantees all of the tile's LDS-DMA pieces have landed;
 * a stage is only overwritten after the tile it held has been read into registers;
@@ -21,10 +21,10 @@ def _kernel_text():
     return s[a:s.index("static int launch_w1", a)]
 
 
-def _consts(bn):
+def _consts(bn, bm=32):
     """P, D and the four wait constants, evaluated from the expressions in the source."""
     k = _kernel_text()
-    env = {"BM": 32, "BN": bn}
+    env = {"BM": bm, "BN": bn}
     env["AP"], env["WP"] = env["BM"] // 8, bn // 8
     env["P"] = env["AP"] + env["WP"]
     m = re.search(r"constexpr int D = ([^;]+);", k)
@@ -54,10 +54,12 @@ class InOrderCounter:
         return bool(idx) and idx[-1] < self.landed
 
 
+@pytest.mark.parametrize("bm", [32, 64])
 @pytest.mark.parametrize("bn", [32, 64, 128])
 @pytest.mark.parametrize("nt", list(range(1, 20)) + [31, 32, 64, 65])
-def test_ring_schedule_of_the_one_wave_kernel(bn, nt):
-    P, D, (w_room, w_first, w_iter, w_end) = _consts(bn)
+def test_ring_schedule_of_the_one_wave_kernel(bn, nt, bm):
+    P, D, (w_room, w_first, w_iter, w_end) = _consts(bn, bm)
+    assert D >= 3
     assert (D - 1) * P + 3 <= 63
     c = InOrderCounter()
     stage_tile = {}           # stage -> tile whose pieces were issued into it last
