@@ -1391,7 +1391,9 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     float* const prm = reinterpret_cast<float*>(smem + D * STAGE_BYTES);
     float* const xch = prm + 5 * BN;
     const int lane = threadIdx.x;
-    const int n0 = blockIdx.x * BN;
+    // workgroup -> (row tile, column tile), column tiles fastest: the row tiles of one column tile are ntn apart and so (ntn a
+    // multiple of 8) on the same XCD, where they find its W rows in L2
+    const int m0 = ((int)blockIdx.x / p.ntn) * BM, n0 = ((int)blockIdx.x % p.ntn) * BN;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
     // descriptors: the BM rows of A per K segment, the BN rows of W
@@ -1412,7 +1414,7 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     i32x4 srd_a;
     auto enter_segment = [&](int s) {
         const unsigned ld = (unsigned)p.lda[s] * 2u;
-        srd_a = make_srd((unsigned long long)p.A[s], (unsigned)(BM - 1) * ld + (unsigned)p.ktiles[s] * 128u);
+        srd_a = make_srd((unsigned long long)p.A[s] + (unsigned long long)m0 * ld, (unsigned)(BM - 1) * ld + (unsigned)p.ktiles[s] * 128u);
 #pragma unroll
         for (int j = 0; j < AP; ++j) {
             const int row = 8 * j + (lane >> 3);
@@ -1502,7 +1504,7 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     }
     if (nt & 1) body(std::integral_constant<int, 0>{});
     wait_vmcnt<0>();   // the repeated pieces of the last iterations too, before the ring's memory is reused
-    Epi::template run<true, (BN >= 64 ? 4 : 2)>(acc, p, 0, n0, 0, 0, 0, lane, reinterpret_cast<float*>(smem), prm, xch);
+    Epi::template run<true, (BN >= 64 ? 4 : 2)>(acc, p, m0, n0, 0, 0, 0, lane, reinterpret_cast<float*>(smem), prm, xch);
 }
 
 template <int BM, int BN>
@@ -1515,7 +1517,8 @@ static int launch_w1(const GemmParams& p, hipStream_t stream) {
     if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmParams q = p;
     q.ntn = p.N / BN;
-    hipLaunchKernelGGL((gemm_w1_bf16_kernel<BM, BN>), dim3(q.ntn), dim3(64), smem, stream, q);
+    const int row_tiles = (p.m_valid + BM - 1) / BM;   // row tiles of padding only are not launched
+    hipLaunchKernelGGL((gemm_w1_bf16_kernel<BM, BN>), dim3(row_tiles * q.ntn), dim3(64), smem, stream, q);
     return check_launch("gemm (one wave per tile)");
 }
 
@@ -1663,11 +1666,13 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
                      : a.tile_hint == 2568 ? launch256w<8>(p, stream) : launch256w<4>(p, stream);
         return launch256(p, pipelined, stream);
     }
-    // at most 64 live rows (the generator's default batch is 32): the one-wave kernel, 32 or 64 rows and 32 columns per workgroup
+    // few live rows (the generator's default batch is 32): the one-wave kernel, 32 or 64 rows and 32 columns per workgroup
     // where every GroupNorm group fits in 32, else 64 or 128 (a batch-32 sampling run takes 24 % less time than on the tile kernels); tile_hint 32
     // asks for it, any other hint (or the measurement aid ADCDIFF_GEMM_W1=0) for the tile kernels
     static const bool w1_default = [] { const char* e = getenv("ADCDIFF_GEMM_W1"); return e ? atoi(e) != 0 : true; }();
-    if (a.dtype == ADCDIFF_BF16 && p.m_valid <= 64 && p.ksplit == 1 && (a.tile_hint == 32 || (a.tile_hint == 0 && w1_default))) {
+    // up to 1024 rows (16 row tiles of 64): 12 % less time per sampling step than the 128-row tile kernels at batches of 128 to 1024
+    static const int w1_rows = [] { const char* e = getenv("ADCDIFF_GEMM_W1_ROWS"); return e ? atoi(e) : 1024; }();   // measurement aid
+    if (a.dtype == ADCDIFF_BF16 && p.m_valid >= 1 && p.ksplit == 1 && (a.tile_hint == 32 || (a.tile_hint == 0 && w1_default && p.m_valid <= w1_rows))) {
         int gmax = 0;
         for (int g = 0; g < a.n_gn; ++g) gmax = a.gn[g].group_size > gmax ? a.gn[g].group_size : gmax;
         const bool r32 = p.m_valid <= 32;

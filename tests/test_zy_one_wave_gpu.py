@@ -1,5 +1,5 @@
-"""GPU parity of the one-wave GEMM kernel for batches of at most 64 rows, through the C ABI (via adcdiff.ops).
-Bit-exact against the tile kernels, which the other kernel tests pin to the oracle; the sampler tests at batch <= 64 run
+"""GPU parity of the one-wave GEMM kernel for batches of at most 1024 rows, through the C ABI (via adcdiff.ops).
+Bit-exact against the tile kernels, which the other kernel tests pin to the oracle; the sampler tests at batch <= 1024 run
 through the same kernel and pin it to the golden rows."""
 import numpy as np
 import pytest
@@ -26,10 +26,11 @@ def _bf16_round(a):
                                                ([64, 64], 192, (32, 32), 1), ([2048], 512, (64, 64), 32), ([4096, 64], 256, (8, 8), 31),
                                                ([192, 64, 64], 64, (16, 16), 32), ([512, 1024], 256, (128, 8), 32), ([64], 128, (128, 128), 17),
                                                ([2048, 1024], 384, (64, 128), 32), ([128, 64, 192], 256, (16, 32), 64), ([512, 1024], 128, (8, 64), 33),
-                                               ([2048, 1024], 384, (64, 128), 50), ([64], 64, (4, 64), 64), ([4096, 64], 256, (8, 8), 47)])
+                                               ([2048, 1024], 384, (64, 128), 50), ([64], 64, (4, 64), 64), ([4096, 64], 256, (8, 8), 47),
+                                               ([512, 1024], 256, (128, 8), 100), ([128, 64, 192], 256, (16, 32), 128), ([2048], 512, (64, 64), 65)])
 def test_one_wave_kernel_for_32_rows_equals_the_tile_kernels(Ks, N, gs_pair, live):
     hint = 32
-    """Launches with at most 64 live rows default to a kernel with one wave per workgroup (32 rows x 32 or 64 columns;
+    """Launches with at most 1024 live rows default to a kernel with one wave per workgroup (32 rows x 32 or 64 columns;
     tile_hint 32 asks for it): every output -- float32, operand type, both SiLU(GroupNorm) outputs, with bias, gathered row bias and
     residual -- equals the 128-row tile kernel's bit for bit on the live rows, for one and several K segments, rings
     shorter and longer than the prefetch depth, and the reverse-step update in the epilogue."""
