@@ -1354,9 +1354,9 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
 // the fragment reads of tile t + 1 into the other register set.  Every iteration issues the same instructions: past the last
 // tile the pieces of the last tile go out again (into stages nobody reads), which keeps the vmcnt arithmetic constant.
 // M0 is left at the last LDS-DMA address: the compiler has no use for it in this kernel.
-// What bounds a tile now is the LDS-DMA path itself, about 40 cycles per 1 KiB piece and CU (the four-wave kernel pays the same
-// 42): a four-stage ring, a third fewer scalar instructions, a padded row pitch of W and a split into a loader and a compute
-// wave all left the tile time where it was.
+// What bounds a tile now is the rate at which one CU gets lines from beyond its L2, about 48 GB/s: the tile time is proportional
+// to the tile's bytes (8 KiB 0.17 us, 12 KiB 0.24 us, 20 KiB 0.40 us); a four-stage ring, a third fewer scalar instructions and a
+// padded row pitch of W all left it where it was.
 // Fragments, K order and epilogue are those of the tile kernels: bit-identical results.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -1522,6 +1522,160 @@ static int launch_w1(const GemmParams& p, hipStream_t stream) {
     return check_launch("gemm (one wave per tile)");
 }
 
+// ---- the same tile with loader waves: wave 0 reads fragments, multiplies and runs the epilogue, waves 1 .. P / 4 issue the LDS-DMA --
+// The lone wave above issues all 8 to 24 pieces of a tile between its MFMAs.  Here every group of four pieces (one M0 write) has a
+// wave of its own with its
+// own ring bookkeeping and vmcnt, and the waves meet at ONE barrier per K tile: a loader arrives when its part of tile t has landed,
+// wave 0 when its fragment reads of tile t - 1 have returned, after which the loaders refill the stage of tile t - 1.  Every wave
+// runs exactly nt barriers.  Fragments, K order and epilogue as in the other kernels: bit-identical results.
+template <int BM, int BN>
+__global__ __launch_bounds__(64 * (1 + (BM + BN) / 32)) void gemm_cl_bf16_kernel(const GemmParams p) {
+    typedef bf16_t T;
+    constexpr int TM = BM / 16, TN = BN / 16;
+    constexpr int AP = BM / 8, WP = BN / 8, P = AP + WP;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int D = 147456 / STAGE_BYTES < 8 ? 147456 / STAGE_BYTES : 8;   // ring stages; a loader has (D - 1) * 4 pieces in flight
+    constexpr int NM = 2 * TM * TN, NR = 2 * (TM + TN);
+    static_assert(NR <= NM && D >= 3 && D - 2 <= 7 && AP % 4 == 0 && WP % 4 == 0, "ring geometry");
+    typedef Epilogue<T, 64, BN, BM, BN, TM, TN> Epi;
+    static_assert(D * STAGE_BYTES >= Epi::STAGE_BYTES, "the epilogue stages through the ring's memory");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const prm = reinterpret_cast<float*>(smem + D * STAGE_BYTES);
+    float* const xch = prm + 5 * BN;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = ((int)blockIdx.x / p.ntn) * BM, n0 = ((int)blockIdx.x % p.ntn) * BN;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int nt = p.nt_total;
+
+    if (wave != 0) {
+        // ---- loader: pieces 4 (wave - 1) .. + 3 of every tile, all of them A rows or all of them W rows
+        const int first = 4 * (wave - 1);
+        const bool loads_a = first < AP;
+        const int row0 = 8 * (loads_a ? first : first - AP);   // first row of this wave's 32 rows inside the operand's tile
+        auto make_srd = [](unsigned long long base, unsigned bytes) {
+            return i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)base), __builtin_amdgcn_readfirstlane((int)((unsigned)(base >> 32) & 0xffffu)),
+                         __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+        };
+        i32x4 srd;
+        int voff[4];   // lane offsets of the four pieces, 1024 j lower for the instruction offset
+        auto enter_segment = [&](int sg) {   // A: K segment sg; W: its single segment
+            const unsigned ld = loads_a ? (unsigned)p.lda[sg] * 2u : (unsigned)p.ldw * 2u;
+            const unsigned long long base = loads_a ? (unsigned long long)p.A[sg] + (unsigned long long)m0 * ld
+                                                    : (unsigned long long)p.W + (unsigned long long)n0 * ld;
+            const int kt = loads_a ? p.ktiles[sg] : nt;
+            srd = make_srd(base, (unsigned)((loads_a ? BM : BN) - 1) * ld + (unsigned)kt * 128u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = row0 + 8 * j + (lane >> 3);
+                voff[j] = (int)((unsigned)row * ld + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16)) - 1024 * j;
+            }
+        };
+        enter_segment(0);
+        int seg = 0, tt = 0;
+        auto issue = [&](int stage) {   // the next tile into `stage`
+            if (loads_a && tt == p.ktiles[seg]) {
+                ++seg; tt = 0;
+                if (tt == p.ktiles[seg]) ++seg;
+                enter_segment(seg);
+            }
+            const int so = tt * 128;
+            const unsigned dst = lds0 + (unsigned)stage * STAGE_BYTES + (unsigned)first * 1024u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma_piece(j, voff[j], srd, so, dst);
+            ++tt;
+        };
+#pragma unroll
+        for (int k = 0; k < D - 1; ++k)
+            if (k < nt) issue(k);
+        int stage = D - 1;   // of tile t - 1 + D: the never-used last stage at t = 0, then the stage of tile t - 1
+        for (int t = 0; t < nt; ++t) {
+            const int ahead = (nt < t + D - 1 ? nt : t + D - 1) - (t + 1);   // tiles issued after tile t
+            wait_tiles_in_flight<4>(ahead);                                   // this wave's part of tile t has landed
+            __builtin_amdgcn_s_barrier();                                     // ... everyone's has, and wave 0 has read tile t - 1
+            if (t + D - 1 < nt) issue(stage);
+            stage = stage == D - 1 ? 0 : stage + 1;
+        }
+        return;
+    }
+
+    // ---- compute wave
+    Epi::stage_params(p, n0, lane, prm);
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int frow = lane & 15, fchunk = lane >> 4;
+    uint4 fa[2][2][TM], fb[2][2][TN];
+    auto read_frag = [&](auto SET, int m, const char* stage) {
+        constexpr int S = decltype(SET)::value;
+        const int ks = m / (TM + TN), r = m % (TM + TN);
+        const int c = 4 * ks + fchunk;
+        const int row = (r < TM ? r : r - TM) * 16 + frow;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + (r < TM ? 0 : BM * 128) + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        if (r < TM) fa[S][ks][r] = v; else fb[S][ks][r - TM] = v;
+    };
+    auto mfma = [&](auto SET, int m) {
+        constexpr int S = decltype(SET)::value;
+        const int ks = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[S][ks][i]), __builtin_bit_cast(bf16x8, fb[S][ks][j]),
+                                                            acc[i][j], 0, 0, 0);
+    };
+    int slot = 0;   // stage of the tile read next
+    auto next_stage = [&]() { const char* const st = smem + slot * STAGE_BYTES; slot = slot == D - 1 ? 0 : slot + 1; return st; };
+    __builtin_amdgcn_s_barrier();   // tile 0
+    {
+        const char* const st = next_stage();
+#pragma unroll
+        for (int m = 0; m < NR; ++m) read_frag(std::integral_constant<int, 0>{}, m, st);
+    }
+    // tile t into set S while the MFMAs of tile t - 1 run from the other set
+    auto body = [&](auto SET) {
+        constexpr int S = decltype(SET)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of tile t - 1 have returned: its stage may be refilled
+        __builtin_amdgcn_s_barrier();
+        const char* const st = next_stage();
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            mfma(std::integral_constant<int, S ^ 1>{}, m);
+            if (m < NR) read_frag(SET, m, st);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int t = 1;
+    for (; t + 1 < nt; t += 2) {
+        body(std::integral_constant<int, 1>{});
+        body(std::integral_constant<int, 0>{});
+    }
+    if (t < nt) {
+        body(std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int m = 0; m < NM; ++m) mfma(std::integral_constant<int, 1>{}, m);
+    } else {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) mfma(std::integral_constant<int, 0>{}, m);
+    }
+    // every tile had landed before the last barrier and this wave's reads have returned: the ring's memory is free
+    Epi::template run<true, (BN >= 64 ? 4 : 2)>(acc, p, m0, n0, 0, 0, 0, lane, reinterpret_cast<float*>(smem), prm, xch);
+}
+
+template <int BM, int BN>
+static int launch_cl(const GemmParams& p, hipStream_t stream) {
+    typedef Epilogue<bf16_t, 64, BN, BM, BN, BM / 16, BN / 16> Epi;
+    constexpr int STAGE = (BM + BN) * 128, D = 147456 / STAGE < 8 ? 147456 / STAGE : 8;
+    constexpr int smem = D * STAGE + Epi::EXTRA_BYTES;
+    static_assert(smem <= 160 * 1024, "LDS of a CU");
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_cl_bf16_kernel<BM, BN>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    GemmParams q = p;
+    q.ntn = p.N / BN;
+    const int row_tiles = (p.m_valid + BM - 1) / BM;
+    hipLaunchKernelGGL((gemm_cl_bf16_kernel<BM, BN>), dim3(row_tiles * q.ntn), dim3(64 * (1 + (BM + BN) / 32)), smem, stream, q);
+    return check_launch("gemm (compute wave + loader waves)");
+}
+
 template <typename T, int BM, int BN, int NSTAGE>
 static int launch(const GemmParams& p, hipStream_t stream) {
     constexpr int TS = sizeof(T) == 2 ? 16 : 32;
@@ -1672,10 +1826,19 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     static const bool w1_default = [] { const char* e = getenv("ADCDIFF_GEMM_W1"); return e ? atoi(e) != 0 : true; }();
     // up to 1024 rows (16 row tiles of 64): 12 % less time per sampling step than the 128-row tile kernels at batches of 128 to 1024
     static const int w1_rows = [] { const char* e = getenv("ADCDIFF_GEMM_W1_ROWS"); return e ? atoi(e) : 1024; }();   // measurement aid
-    if (a.dtype == ADCDIFF_BF16 && p.m_valid >= 1 && p.ksplit == 1 && (a.tile_hint == 32 || (a.tile_hint == 0 && w1_default && p.m_valid <= w1_rows))) {
+    if (a.dtype == ADCDIFF_BF16 && p.m_valid >= 1 && p.ksplit == 1 && (a.tile_hint == 32 || a.tile_hint == 325 || (a.tile_hint == 0 && w1_default && p.m_valid <= w1_rows))) {
         int gmax = 0;
         for (int g = 0; g < a.n_gn; ++g) gmax = a.gn[g].group_size > gmax ? a.gn[g].group_size : gmax;
         const bool r32 = p.m_valid <= 32;
+        // the variant with loader waves where it is the faster one: 32 rows and tiles of 64 or 128 columns (-10 % / -19 % per launch);
+        // with 32 columns it loses, and 64-row tiles wider than 32 columns would spill (more than four waves leave the compute
+        // wave 256 registers).  325 = that variant wherever it exists, 32 = never (measurement aids)
+        static const bool cl_default = [] { const char* e = getenv("ADCDIFF_GEMM_CL"); return e ? atoi(e) != 0 : true; }();
+        if (a.tile_hint == 325 || (a.tile_hint == 0 && cl_default)) {
+            if (gmax <= 32 && a.tile_hint == 325) return r32 ? launch_cl<32, 32>(p, stream) : launch_cl<64, 32>(p, stream);
+            if (gmax > 32 && gmax <= 64 && r32) return launch_cl<32, 64>(p, stream);
+            if (gmax > 64 && r32 && a.N % 128 == 0) return launch_cl<32, 128>(p, stream);
+        }
         if (gmax <= 32) return r32 ? launch_w1<32, 32>(p, stream) : launch_w1<64, 32>(p, stream);
         if (gmax <= 64) return r32 ? launch_w1<32, 64>(p, stream) : launch_w1<64, 64>(p, stream);
         // groups of 128 channels: the two halves of 64 meet inside a 16-lane row

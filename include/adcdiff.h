@@ -115,7 +115,7 @@ typedef struct adcdiff_gemm_args {
                                   kernel; 2560 / 2561 = its phased / ring main loop; 2564 = the four-wave 256 x 256 kernel with the
                                   assembly main loop, which 0 picks for large bf16 layers); 1 / 3 = force the 128-row kernel with one
                                   LDS stage / the three-stage ring (A/B measurements, tests); 32 = the one-wave kernel for bf16
-                                  launches (any m_valid), which 0 picks up to 1024 live rows */
+                                  launches (any m_valid), which 0 picks up to 1024 live rows; 325 = its variant with loader waves where one exists */
     int split_k;               /* 0 / 1 = off.  S > 1: the K dimension (one segment, a multiple of S * 64 bf16 / S * 32 f32) is cut
                                   into S equal slices computed by separate workgroups; slice s writes its partial product to
                                   out_f32 + s * split_stride and the caller sums the S partials in a fixed order.  For

@@ -28,8 +28,8 @@ def _bf16_round(a):
                                                ([2048, 1024], 384, (64, 128), 32), ([128, 64, 192], 256, (16, 32), 64), ([512, 1024], 128, (8, 64), 33),
                                                ([2048, 1024], 384, (64, 128), 50), ([64], 64, (4, 64), 64), ([4096, 64], 256, (8, 8), 47),
                                                ([512, 1024], 256, (128, 8), 100), ([128, 64, 192], 256, (16, 32), 128), ([2048], 512, (64, 64), 65)])
-def test_one_wave_kernel_for_32_rows_equals_the_tile_kernels(Ks, N, gs_pair, live):
-    hint = 32
+@pytest.mark.parametrize("hint", [32, 325])
+def test_one_wave_kernel_for_32_rows_equals_the_tile_kernels(Ks, N, gs_pair, live, hint):
     """Launches with at most 1024 live rows default to a kernel with one wave per workgroup (32 rows x 32 or 64 columns;
     tile_hint 32 asks for it): every output -- float32, operand type, both SiLU(GroupNorm) outputs, with bias, gathered row bias and
     residual -- equals the 128-row tile kernel's bit for bit on the live rows, for one and several K segments, rings
