@@ -1826,23 +1826,28 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     static const bool w1_default = [] { const char* e = getenv("ADCDIFF_GEMM_W1"); return e ? atoi(e) != 0 : true; }();
     // up to 1024 rows (16 row tiles of 64): 12 % less time per sampling step than the 128-row tile kernels at batches of 128 to 1024
     static const int w1_rows = [] { const char* e = getenv("ADCDIFF_GEMM_W1_ROWS"); return e ? atoi(e) : 1024; }();   // measurement aid
-    if (a.dtype == ADCDIFF_BF16 && p.m_valid >= 1 && p.ksplit == 1 && (a.tile_hint == 32 || a.tile_hint == 325 || (a.tile_hint == 0 && w1_default && p.m_valid <= w1_rows))) {
+    if (a.dtype == ADCDIFF_BF16 && p.m_valid >= 1 && p.ksplit == 1 && (a.tile_hint == 0 || a.tile_hint == 32 || a.tile_hint == 325)) {
         int gmax = 0;
         for (int g = 0; g < a.n_gn; ++g) gmax = a.gn[g].group_size > gmax ? a.gn[g].group_size : gmax;
+        const int bn = gmax <= 32 ? 32 : gmax <= 64 ? 64 : 128;
         const bool r32 = p.m_valid <= 32;
+        // by default not for launches with thousands of such tiles (the [1000, 9984] time-projection table of a training step):
+        // there the 128-row tile kernels' reuse of W wins
+        const bool take = a.tile_hint != 0 || (w1_default && p.m_valid <= w1_rows && (long)((p.m_valid + 63) / 64) * (a.N / bn) <= 1024);
         // the variant with loader waves where it is the faster one: 32 rows and tiles of 64 or 128 columns (-10 % / -19 % per launch);
         // with 32 columns it loses, and 64-row tiles wider than 32 columns would spill (more than four waves leave the compute
         // wave 256 registers).  325 = that variant wherever it exists, 32 = never (measurement aids)
         static const bool cl_default = [] { const char* e = getenv("ADCDIFF_GEMM_CL"); return e ? atoi(e) != 0 : true; }();
-        if (a.tile_hint == 325 || (a.tile_hint == 0 && cl_default)) {
-            if (gmax <= 32 && a.tile_hint == 325) return r32 ? launch_cl<32, 32>(p, stream) : launch_cl<64, 32>(p, stream);
-            if (gmax > 32 && gmax <= 64 && r32) return launch_cl<32, 64>(p, stream);
-            if (gmax > 64 && r32 && a.N % 128 == 0) return launch_cl<32, 128>(p, stream);
+        if (take && a.N % bn == 0) {
+            if (a.tile_hint == 325 || (a.tile_hint == 0 && cl_default)) {
+                if (bn == 32 && a.tile_hint == 325) return r32 ? launch_cl<32, 32>(p, stream) : launch_cl<64, 32>(p, stream);
+                if (bn == 64 && r32) return launch_cl<32, 64>(p, stream);
+                if (bn == 128 && r32) return launch_cl<32, 128>(p, stream);   // the two halves of a 128-channel group meet inside a 16-lane row
+            }
+            if (bn == 32) return r32 ? launch_w1<32, 32>(p, stream) : launch_w1<64, 32>(p, stream);
+            if (bn == 64) return r32 ? launch_w1<32, 64>(p, stream) : launch_w1<64, 64>(p, stream);
+            return r32 ? launch_w1<32, 128>(p, stream) : launch_w1<64, 128>(p, stream);
         }
-        if (gmax <= 32) return r32 ? launch_w1<32, 32>(p, stream) : launch_w1<64, 32>(p, stream);
-        if (gmax <= 64) return r32 ? launch_w1<32, 64>(p, stream) : launch_w1<64, 64>(p, stream);
-        // groups of 128 channels: the two halves of 64 meet inside a 16-lane row
-        if (a.N % 128 == 0) return r32 ? launch_w1<32, 128>(p, stream) : launch_w1<64, 128>(p, stream);
     }
     // few workgroups: nothing else on the CU hides a tile's load latency, so take the three-stage ring
     const int bn = small ? 64 : wide ? 128 : 64, bm = small || mid ? 64 : 128;
