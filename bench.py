@@ -5,7 +5,7 @@
 
 Workloads (emb 512 / hidden 256, random weights of that architecture, inputs generated on the device):
 
-* ``bf16_b65536`` (default; BASELINE configs[2]) and ``fp32_b4096`` (configs[1]): one "step" is one full pass of the hot
+* ``bf16_b65536`` (default; BASELINE configs[2]), ``fp32_b4096`` (configs[1]) and ``bf16_b32`` (the generator's own call): one "step" is one full pass of the hot
   path over one batch -- the T = 1000 reverse loop (p_sample_loop: denoiser forward + fused schedule update per timestep)
   on `batch` samples per GPU.  With N > 1 every rank samples its own rows (counter-RNG row offset = rank * batch, so the
   job equals one N * batch-row run) and the latents are collected by one RCCL all-gather inside the timed region
@@ -40,6 +40,7 @@ WORKLOADS = {
     "fp32_b4096": ("fp32", 4096, "configs[1]: same denoiser, fp32 on 1 MI355X, batch 4096"),
     "shard_1m": ("bf16", 1048576, "configs[3]: 1M samples sharded over the GPUs, RCCL all-gather of latents"),
     "train_dp": ("bf16", 4096, "configs[4]: denoiser train step (q_sample noise-pred loss fwd+bwd), data parallel, batch 4096 per GPU"),
+    "bf16_b32": ("bf16", 32, "the generator's own call (molecule_generator.py:238-262): 32 latents per call, bf16"),
 }
 DIMS = (512, 256, 512)
 ALGO_FLOP_PER_SAMPLE_STEP = 81.92e6     # 2 * 40 960 000 MACs: denoiser linears with the time term hoisted
@@ -124,6 +125,17 @@ def summarize_records(records, dtype, units, algo_flop_per_unit, workload):
     w4 = [r for r in gemm if r["kind"] == _lib.KIND_GEMM_BF16_W256]
     big = [r for r in gemm if r["kind"] == _lib.KIND_GEMM_BF16_T256]
     small_name = "gemm_nt_kernel<%s>" % ("bf16" if dtype == "bf16" else "float")
+    if workload == "bf16_b32":
+        # a batch of 32 streams the weights once per step through the few-row kernels: bound by bytes, not by the matrix cores
+        dom_ms, dom_by = sum(r["ms"] for r in gemm), sum(r["bytes"] for r in gemm)
+        window_ms = sum(r["ms"] for r in records)
+        main = {"bound": "hbm", "kernel": "gemm_w1_bf16_kernel / gemm_cl_bf16_kernel", "achieved": round(dom_by / (dom_ms * 1e-3) / 1e9, 1),
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dom_by / (dom_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                "launches": len(gemm), "avg_launch_ms": round(dom_ms / max(1, len(gemm)), 4),
+                "algorithmic_bytes_per_launch": dom_by / max(1, len(gemm)), "share_of_window": round(dom_ms / max(1e-9, window_ms), 3),
+                "timing": "hipEvent in front of every launch on the launch stream, span to the next launch's event, minus the per-event cost "
+                          "measured against the same window between one event pair"}
+        return {"roofline": main}
     if w4:
         dom, dom_name, dom_key = w4, "gemm256w_bf16_kernel", "gemm256w_kernel<bf16>"
     elif big:
