@@ -66,6 +66,8 @@ static void carve_arena(adcdiff_unet* n, void* arena, size_t cap) {
     n->wtp_all = (float*)a.take((size_t)n->sumN * n->H * 4);
     n->btp_all = (float*)a.take((size_t)n->sumN * 4);
     n->tb_table = (float*)a.take((size_t)n->Tp * n->sumN * 4);
+    n->s_cond = (float*)a.take((size_t)n->Tp * n->H * 4);
+    n->tb_cond = (float*)a.take((size_t)n->Tp * n->sumN * 4);
     n->pack_table = (PackItem*)a.take(PACK_MAX_ITEMS * sizeof(PackItem));
     n->arena_used = a.off;
 }
@@ -327,8 +329,12 @@ struct StepFold {
     bool have_in;
 };
 
+// tb_table: the [T, sumN] table of every block's time_proj output per timestep that the row bias comes from when there is no
+// per-row condition: the plan's (no condition) or the caller's (one condition row for the whole batch, uniform_cond_table)
 int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform, const float* cemb,
-                  int ldce, float* eps, int lde, Bump& ws, bool dry, hipStream_t st, const StepFold* fold = nullptr) {
+                  int ldce, float* eps, int lde, Bump& ws, bool dry, hipStream_t st, const StepFold* fold = nullptr,
+                  const float* tb_table = nullptr) {
+    if (!tb_table) tb_table = n->tb_table;
     const int Bp = (int)round_up((size_t)B, 128);
     const size_t e = (size_t)n->esz;
     const int H = n->H, dt = n->dtype;
@@ -369,8 +375,8 @@ int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t
                 g.bias = b.bias1_cond;
             } else {
                 g.bias = b.bias1;
-                if (t_rows) { g.rowbias = n->tb_table + b.tb_off; g.ldrb = n->sumN; g.rowbias_idx = t_rows; g.rowbias_rows = n->T; }
-                else { g.rowbias = n->tb_table + (size_t)t_uniform * n->sumN + b.tb_off; g.ldrb = 0; }
+                if (t_rows) { g.rowbias = tb_table + b.tb_off; g.ldrb = n->sumN; g.rowbias_idx = t_rows; g.rowbias_rows = n->T; }
+                else { g.rowbias = tb_table + (size_t)t_uniform * n->sumN + b.tb_off; g.ldrb = 0; }
             }
             g.n_gn = 1; g.gn_eps = 1e-5f;
             g.gn[0] = adcdiff_gn_out{q.norm2_w, q.norm2_b, a2, b.cout, b.gs2};
@@ -444,6 +450,18 @@ size_t forward_bytes(adcdiff_unet* n, int B) {
     return ws.off + round_up(Bp * n->O * 4, 256) + round_up(Bp * n->D * n->esz, 256) + round_up(Bp * n->H * n->esz, 256);
 }
 
+// One condition row for the whole batch (the caller passes ldce = 0; molecule_generator.py:238-245 expands one protein's features
+// to the batch): t_emb + c_emb is then the same for every row, so time_proj(SiLU(t_emb + c_emb)) is a row bias per timestep, as
+// without a condition, instead of a K segment of every block's first GEMM.  Built once per call for all T timesteps in float32,
+// like the plan's own table (two launches, ~70 us), in the plan's second table: calls that share a plan must share a stream.
+int uniform_cond_table(adcdiff_unet* n, const float* cemb, hipStream_t st) {
+    TRY(temb_silu(n->te_table, n->H, n->Tp, nullptr, -1, cemb, 0, ADCDIFF_F32, n->s_cond, n->H, n->Tp, n->H, st));
+    adcdiff_gemm_args g = gemm_args(ADCDIFF_F32, n->Tp, 0, n->sumN);
+    g.nseg = 1; g.A[0] = n->s_cond; g.lda[0] = n->H; g.K[0] = n->H; g.W = n->wtp_all; g.ldw = n->H; g.bias = n->btp_all;
+    g.out_f32 = n->tb_cond; g.ldo_f32 = n->sumN;
+    return gemm_dispatch(g, st);
+}
+
 int check_forward_args(adcdiff_unet* n, const char* who, int B, const void* ws, size_t ws_bytes) {
     if (!n) return fail(ADCDIFF_E_BADARG, "%s: null plan", who);
     if (!n->packed) return fail(ADCDIFF_E_BADARG, "%s: adcdiff_unet_pack has not been called", who);
@@ -501,8 +519,14 @@ extern "C" int adcdiff_ddpm_sample_loop(adcdiff_unet* n, float* x, int ldx, int 
     TRY(check_forward_args(n, "ddpm_sample_loop", B, workspace, workspace_bytes));
     if (!x || !coef || ldx < n->D || !aligned16(x) || ldx % 4) return fail(ADCDIFF_E_BADARG, "ddpm_sample_loop: bad x / coef");
     if (t_start >= n->T || t_stop < 0 || t_stop > t_start) return fail(ADCDIFF_E_BADARG, "ddpm_sample_loop: steps %d..%d outside 0..%d", t_start, t_stop, n->T - 1);
-    if (cemb && (ldce < n->H || !aligned16(cemb))) return fail(ADCDIFF_E_BADARG, "ddpm_sample_loop: bad condition embedding");
+    if (cemb && ((ldce != 0 && ldce < n->H) || !aligned16(cemb))) return fail(ADCDIFF_E_BADARG, "ddpm_sample_loop: bad condition embedding");
     const int Bp = (int)round_up((size_t)B, 128);
+    const float* tb_table = nullptr;
+    if (cemb && ldce == 0 && n->fused) {
+        TRY(uniform_cond_table(n, cemb, as_stream(stream_)));
+        tb_table = n->tb_cond;
+        cemb = nullptr;
+    }
     for (int t = t_start; t >= t_stop; --t) {
         Bump ws(workspace, workspace_bytes);
         float* eps = (float*)ws.take((size_t)Bp * n->O * 4);
@@ -514,10 +538,11 @@ extern "C" int adcdiff_ddpm_sample_loop(adcdiff_unet* n, float* x, int ldx, int 
             f.upd.x = x; f.upd.ldx = ldx; f.upd.noise = nz; f.upd.ldn = n->O;
             f.upd.seed = seed; f.upd.step = (uint32_t)t; f.upd.row_offset = row_offset;
             f.x_out = x; f.have_in = t != t_start;
-            TRY(forward_fused(n, x, ldx, B, nullptr, t, cemb, ldce, nullptr, 0, ws, false, as_stream(stream_), &f));
+            TRY(forward_fused(n, x, ldx, B, nullptr, t, cemb, ldce, nullptr, 0, ws, false, as_stream(stream_), &f, tb_table));
             continue;
         }
-        TRY(forward_impl(n, x, ldx, B, nullptr, t, cemb, ldce, eps, n->O, ws, false, as_stream(stream_)));
+        if (tb_table) TRY(forward_fused(n, x, ldx, B, nullptr, t, nullptr, 0, eps, n->O, ws, false, as_stream(stream_), nullptr, tb_table));
+        else TRY(forward_impl(n, x, ldx, B, nullptr, t, cemb, ldce, eps, n->O, ws, false, as_stream(stream_)));
         TRY(adcdiff_ddpm_step(x, ldx, eps, n->O, nz, n->O, x, ldx, B, n->O, coef[t], seed, (uint32_t)t, row_offset, stream_));
     }
     return ADCDIFF_OK;
@@ -530,8 +555,14 @@ extern "C" int adcdiff_ddim_sample_loop(adcdiff_unet* n, float* x, int ldx, int 
     TRY(check_forward_args(n, "ddim_sample_loop", B, workspace, workspace_bytes));
     if (!x || !coef || !timesteps || nsteps <= 0 || ldx < n->D || !aligned16(x) || ldx % 4)
         return fail(ADCDIFF_E_BADARG, "ddim_sample_loop: bad x / coef / timesteps");
-    if (cemb && (ldce < n->H || !aligned16(cemb))) return fail(ADCDIFF_E_BADARG, "ddim_sample_loop: bad condition embedding");
+    if (cemb && ((ldce != 0 && ldce < n->H) || !aligned16(cemb))) return fail(ADCDIFF_E_BADARG, "ddim_sample_loop: bad condition embedding");
     const int Bp = (int)round_up((size_t)B, 128);
+    const float* tb_table = nullptr;
+    if (cemb && ldce == 0 && n->fused) {
+        TRY(uniform_cond_table(n, cemb, as_stream(stream_)));
+        tb_table = n->tb_cond;
+        cemb = nullptr;
+    }
     for (int i = 0; i < nsteps; ++i) {
         const int t = timesteps[i];
         if (t < 0 || t >= n->T) return fail(ADCDIFF_E_BADARG, "ddim_sample_loop: timestep %d outside 0..%d", t, n->T - 1);
@@ -546,10 +577,11 @@ extern "C" int adcdiff_ddim_sample_loop(adcdiff_unet* n, float* x, int ldx, int 
             f.upd.x = x; f.upd.ldx = ldx; f.upd.noise = nz; f.upd.ldn = n->O;
             f.upd.seed = seed; f.upd.step = (uint32_t)t; f.upd.row_offset = row_offset;
             f.x_out = x; f.have_in = i != 0;
-            TRY(forward_fused(n, x, ldx, B, nullptr, t, cemb, ldce, nullptr, 0, ws, false, as_stream(stream_), &f));
+            TRY(forward_fused(n, x, ldx, B, nullptr, t, cemb, ldce, nullptr, 0, ws, false, as_stream(stream_), &f, tb_table));
             continue;
         }
-        TRY(forward_impl(n, x, ldx, B, nullptr, t, cemb, ldce, eps, n->O, ws, false, as_stream(stream_)));
+        if (tb_table) TRY(forward_fused(n, x, ldx, B, nullptr, t, nullptr, 0, eps, n->O, ws, false, as_stream(stream_), nullptr, tb_table));
+        else TRY(forward_impl(n, x, ldx, B, nullptr, t, cemb, ldce, eps, n->O, ws, false, as_stream(stream_)));
         TRY(adcdiff_ddim_step(x, ldx, eps, n->O, nz, n->O, x, ldx, B, n->O, coef[i], seed, (uint32_t)t, row_offset, stream_));
     }
     return ADCDIFF_OK;

@@ -92,6 +92,7 @@ struct adcdiff_unet {
     int dtype, esz, D, H, O, T, Tp, sumN;
     adcdiff::BlockPlan blk[10];
     float *sin_table, *te_pre, *te_hidden, *te_table, *s_table, *wtp_all, *btp_all, *tb_table;
+    float *s_cond, *tb_cond;   // the sampling loops' table for a one-row condition: SiLU(t_emb + c_emb) and every block's time_proj of it, per timestep
     void *w_out, *w_c0, *w_c2;
     size_t arena_used;
     bool packed;

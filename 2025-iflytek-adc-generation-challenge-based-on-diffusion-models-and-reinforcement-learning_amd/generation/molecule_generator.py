@@ -48,14 +48,16 @@ class MoleculeGenerator:
         self.diffusion_model = diffusion_model
 
     def _expand_condition(self, batch_size: int, protein_features: Optional[torch.Tensor]):
-        """molecule_generator.py:238-245."""
+        """molecule_generator.py:238-245: one protein's features for the whole batch.  The reference repeats the row; here it is
+        expanded (same shape and values, row stride 0), which lets sample() see that the batch shares one condition: the
+        sampling loops then apply the time projection of t_emb + c_emb as a per-timestep row bias instead of a per-row operand."""
         if protein_features is None:
             return None
         condition = protein_features.to(self.device)
         if condition.dim() == 1:
-            condition = condition.unsqueeze(0).repeat(batch_size, 1)
+            condition = condition.unsqueeze(0).expand(batch_size, -1)
         elif condition.shape[0] == 1:
-            condition = condition.repeat(batch_size, 1)
+            condition = condition.expand(batch_size, -1)
         return condition
 
     def _generate_batch_features(self, batch_size: int, protein_features: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:

@@ -415,6 +415,8 @@ class UNetModel(nn.Module):
                                                                                      tuple(condition.shape)))
         if condition.shape[0] not in (1, batch):
             raise ValueError("condition has %d rows for a batch of %d (1 or %d expected)" % (condition.shape[0], batch, batch))
+        if condition.shape[0] > 1 and condition.stride(0) == 0:
+            condition = condition[0].unsqueeze(0)   # one row expanded to the batch (MoleculeGenerator, sample_ddpm_sharded): still one row
         return condition
 
     def _initialize_weights(self):
@@ -441,10 +443,12 @@ class UNetModel(nn.Module):
             raise AdcdiffError("the denoiser runs on an MI355X only (parameters are on %s); no CPU fallback exists" % dev)
         return dev
 
-    def condition_embedding(self, condition, compute_dtype=None, batch=None):
+    def condition_embedding(self, condition, compute_dtype=None, batch=None, broadcast_view=False):
         """condition_embed(condition) (diffusion_model.py:694-698, 765): computed once per sampling call.  With `batch`
         the condition is checked against it and a one-row condition's embedding is repeated to [batch, hidden] (rows of
-        the embedding do not depend on each other, so this equals embedding the repeated condition)."""
+        the embedding do not depend on each other, so this equals embedding the repeated condition); with broadcast_view
+        it stays one row in memory, expanded with a row stride of 0, which is how the sampling loops are told that the
+        whole batch shares the condition (they then turn the time projection into a per-timestep row bias)."""
         dev = self._device()
         eng = self.engine(compute_dtype)
         handle = eng.ensure(dev)
@@ -455,7 +459,9 @@ class UNetModel(nn.Module):
         eng.workspace_for(B, dev)
         cemb = torch.ops.adcdiff.condition_embed(handle.value, cond, self.hidden_dim, eng.workspace)
         if batch is not None and B == 1 and batch > 1:
-            cemb = cemb.expand(batch, -1).contiguous()
+            cemb = cemb.expand(batch, -1)
+            if not broadcast_view:
+                cemb = cemb.contiguous()
         return cemb
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -658,7 +664,7 @@ class DiffusionModel(nn.Module):
         handle = eng.ensure(dev)
         cemb = None
         if condition is not None:
-            cemb = self.model.condition_embedding(condition.to(dev), self.compute_dtype, batch=batch)
+            cemb = self.model.condition_embedding(condition.to(dev), self.compute_dtype, batch=batch, broadcast_view=True)
         ws, ws_bytes = eng.workspace_for(batch, dev)
         return dev, eng, handle, cemb, ws, ws_bytes
 

@@ -75,7 +75,7 @@ def sample_ddpm_sharded(model, total: int, condition: Optional[torch.Tensor] = N
             cond = condition
             if cond.dim() == 1:
                 cond = cond.unsqueeze(0)
-            cond = cond.expand(count, -1) if cond.shape[0] == 1 else cond[first:first + count]
+            cond = cond.expand(count, -1) if cond.shape[0] == 1 else cond[first:first + count]   # a view: sample() sees the shared row
         return model.sample(count, condition=cond, use_ddim=use_ddim, ddim_steps=ddim_steps, eta=eta, seed=seed, row_offset=first)
     return sample_sharded(run, total, group)
 

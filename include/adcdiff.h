@@ -223,14 +223,17 @@ int adcdiff_unet_forward(adcdiff_unet* net, const float* x, int ldx, int B, cons
 /* p_sample_loop (diffusion_model.py:253-261): x holds x_T on entry and the result on return.
  * coef is a HOST array indexed by timestep; steps run t_start, t_start-1, ..., t_stop.
  * noise (optional, device) holds the injected noise of step t at noise + (t_start - t) * noise_step_stride
- * as [B, D] with leading dimension D; NULL selects in-kernel Philox with (seed, row_offset). */
+ * as [B, D] with leading dimension D; NULL selects in-kernel Philox with (seed, row_offset).
+ * cemb: NULL, [B, hidden] with leading dimension ldce >= hidden, or ONE row with ldce = 0 = the whole batch shares the
+ * condition (the generator's case): t_emb + c_emb is then the same for every row and every block's time projection of it
+ * becomes a per-timestep row bias, as without a condition, built once per call in the front of the workspace. */
 int adcdiff_ddpm_sample_loop(adcdiff_unet* net, float* x, int ldx, int B, const float* cemb, int ldce,
                              const adcdiff_ddpm_coef* coef, int t_start, int t_stop, const float* noise,
                              long long noise_step_stride, uint64_t seed, uint64_t row_offset, void* workspace,
                              size_t workspace_bytes, adcdiff_stream_t stream);
 
 /* ddim_sample_loop (diffusion_model.py:325-340): nsteps steps, timesteps[i] / coef[i] HOST arrays in
- * execution order; noise layout as above indexed by execution step i. */
+ * execution order; noise layout as above indexed by execution step i; cemb / ldce as above. */
 int adcdiff_ddim_sample_loop(adcdiff_unet* net, float* x, int ldx, int B, const float* cemb, int ldce,
                              const int* timesteps, const adcdiff_ddim_coef* coef, int nsteps, const float* noise,
                              long long noise_step_stride, uint64_t seed, uint64_t row_offset, void* workspace,

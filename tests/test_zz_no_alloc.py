@@ -3,6 +3,7 @@ library) against the entry point it is a variant of (adcdiff_clip_adamw_step wit
 (ctypes): bit-identical parameters, moments and gradient norm on two calls in a row, the second on a smaller input, and a
 clear error beyond the built-in limit.  Collected last on purpose (file name)."""
 import ctypes as C
+import gc
 
 import numpy as np
 import pytest
@@ -38,6 +39,7 @@ def _run(sizes, seed, noalloc, steps=(1, 2)):
         args = _lib.AdamWArgs(1e-3, 0.9, 0.999, 1e-8, 1e-2, 1.0, step, 1)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         if noalloc:
+            gc.collect()   # garbage of earlier tests (models, workspaces) freed during the call would move the counter too
             before = torch.cuda.memory_allocated()
             _lib.check(lib.adcdiff_clip_adamw_step_noalloc(table.data_ptr(), len(params), chunks, C.byref(args), norm.data_ptr(), stream))
             assert torch.cuda.memory_allocated() == before
