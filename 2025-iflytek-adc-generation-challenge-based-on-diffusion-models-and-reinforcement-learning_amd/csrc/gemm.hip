@@ -1833,7 +1833,11 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         const bool r32 = p.m_valid <= 32;
         // by default not for launches with thousands of such tiles (the [1000, 9984] time-projection table of a training step):
         // there the 128-row tile kernels' reuse of W wins
-        const bool take = a.tile_hint != 0 || (w1_default && p.m_valid <= w1_rows && (long)((p.m_valid + 63) / 64) * (a.N / bn) <= 1024);
+        // a 64-channel group is summed inside one wave here, as in the tile kernels whose wave tile is 64 columns wide; where N is
+        // not a multiple of 128 those are not used at any batch size (the 128 x 64 tile merges two halves of 32, which differs
+        // by a last bit in rare elements), so such launches stay on the tile kernels
+        const bool same_sums = bn != 64 || a.N % 128 == 0;
+        const bool take = same_sums && (a.tile_hint != 0 || (w1_default && p.m_valid <= w1_rows && (long)((p.m_valid + 63) / 64) * (a.N / bn) <= 1024));
         // the variant with loader waves where it is the faster one: 32 rows and tiles of 64 or 128 columns (-10 % / -19 % per launch);
         // with 32 columns it loses, and 64-row tiles wider than 32 columns would spill (more than four waves leave the compute
         // wave 256 registers).  325 = that variant wherever it exists, 32 = never (measurement aids)

@@ -22,11 +22,11 @@ def _bf16_round(a):
     return torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
 
 
-@pytest.mark.parametrize("Ks,N,gs_pair,live", [([64], 64, (4, 64), 32), ([128, 64, 192], 256, (16, 32), 32), ([512, 1024], 128, (8, 64), 17),
+@pytest.mark.parametrize("Ks,N,gs_pair,live", [([64], 128, (4, 64), 32), ([128, 64, 192], 256, (16, 32), 32), ([512, 1024], 128, (8, 64), 17),
                                                ([64, 64], 192, (32, 32), 1), ([2048], 512, (64, 64), 32), ([4096, 64], 256, (8, 8), 31),
                                                ([192, 64, 64], 64, (16, 16), 32), ([512, 1024], 256, (128, 8), 32), ([64], 128, (128, 128), 17),
                                                ([2048, 1024], 384, (64, 128), 32), ([128, 64, 192], 256, (16, 32), 64), ([512, 1024], 128, (8, 64), 33),
-                                               ([2048, 1024], 384, (64, 128), 50), ([64], 64, (4, 64), 64), ([4096, 64], 256, (8, 8), 47),
+                                               ([2048, 1024], 384, (64, 128), 50), ([64], 128, (4, 64), 64), ([4096, 64], 256, (8, 8), 47),
                                                ([512, 1024], 256, (128, 8), 100), ([128, 64, 192], 256, (16, 32), 128), ([2048], 512, (64, 64), 65)])
 @pytest.mark.parametrize("hint", [32, 325])
 def test_one_wave_kernel_for_32_rows_equals_the_tile_kernels(Ks, N, gs_pair, live, hint):
@@ -66,3 +66,41 @@ def test_one_wave_kernel_for_32_rows_equals_the_tile_kernels(Ks, N, gs_pair, liv
                                       update=dict(kind=kind, c=c, x=x.clone(), noise=None, seed=5, step=3, row_offset=40)))
         for o, t in zip(*outs):
             assert torch.equal(o[:live], t[:live])
+
+
+def test_random_shapes_equal_the_tile_kernel():
+    """150 random launches (N, K segments, GroupNorm group sizes, live rows 1 .. M, every epilogue input present or not) through
+    the default choice, the one-wave kernel and its loader-wave variant: every output equals the 128-row tile kernel's on the
+    live rows, bit for bit.  (tools/w1_fuzz.py is the same draw with more cases; it found the one shape class that must stay
+    on the tile kernels: 64-channel groups with N not a multiple of 128.)"""
+    rng = np.random.default_rng(11)
+    torch.manual_seed(11)
+    bf = torch.bfloat16
+    for case in range(150):
+        N = int(rng.choice([64, 128, 192, 256, 384, 512, 1024, 2048]))
+        Ks = [int(rng.choice([64, 128, 192, 256, 512, 1024, 2048])) for _ in range(int(rng.integers(1, 4)))]
+        gss = [g for g in (4, 8, 16, 32, 64, 128) if N % g == 0 and (g <= 64 or N % 128 == 0)]
+        gs = [int(rng.choice(gss)) for _ in range(int(rng.integers(0, 3)))]
+        M = int(rng.choice([128, 256]))
+        live = int(rng.integers(1, M + 1)) if rng.random() < 0.5 else int(rng.integers(1, 65))
+        As = [torch.randn(M, k, device=DEV).to(bf) for k in Ks]
+        W = (torch.randn(N, sum(Ks), device=DEV) / sum(Ks) ** 0.5).to(bf)
+        kw = dict(dtype="bf16", m_valid=live)
+        if rng.random() < 0.7:
+            kw["bias"] = torch.randn(N, device=DEV)
+        if rng.random() < 0.4:
+            kw["rowbias"], kw["rowbias_idx"] = torch.randn(9, N, device=DEV), torch.randint(0, 9, (M,), device=DEV)
+        elif rng.random() < 0.3:
+            kw["rowbias"] = torch.randn(N, device=DEV)
+        if rng.random() < 0.5:
+            kw["residual"] = torch.randn(M, N, device=DEV).to(bf)
+        if rng.random() < 0.5 or not gs:
+            kw["out_op"] = True
+        kw["gn"] = [(torch.rand(N, device=DEV) + 0.5, torch.randn(N, device=DEV), g) for g in gs]
+
+        def flat(r):
+            return list(r) if isinstance(r, (tuple, list)) else [r]
+        ref = flat(ops.gemm(As, W, tile_hint=128, **kw))
+        for hint in (0, 32, 325):
+            for a, b in zip(ref, flat(ops.gemm(As, W, tile_hint=hint, **kw))):
+                assert torch.equal(a[:live], b[:live]), dict(case=case, N=N, Ks=Ks, gs=gs, M=M, live=live, hint=hint)
