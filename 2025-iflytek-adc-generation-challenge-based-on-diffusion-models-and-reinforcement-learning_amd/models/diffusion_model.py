@@ -458,10 +458,11 @@ class UNetModel(nn.Module):
         B = cond.shape[0]
         eng.workspace_for(B, dev)
         cemb = torch.ops.adcdiff.condition_embed(handle.value, cond, self.hidden_dim, eng.workspace)
-        if batch is not None and B == 1 and batch > 1:
-            cemb = cemb.expand(batch, -1)
-            if not broadcast_view:
-                cemb = cemb.contiguous()
+        if batch is not None and B == 1:
+            if broadcast_view:   # row stride 0 for every batch size, 1 included: a row's bits must not depend on the batch
+                cemb = cemb.as_strided((batch, cemb.shape[1]), (0, 1))
+            elif batch > 1:
+                cemb = cemb.expand(batch, -1).contiguous()
         return cemb
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None) -> torch.Tensor:
