@@ -355,6 +355,7 @@ class UNetModel(nn.Module):
         self.num_timesteps = num_timesteps
         self.enable_memory_efficient_attention = enable_memory_efficient_attention
         self.compute_dtype = compute_dtype
+        self.detect_shared_condition = False   # config key 'detect_shared_condition' of DiffusionModel, see expand_condition
         if input_dim <= 0:
             raise ValueError("input_dim must be positive")
         self.time_embed = TimeEmbedding(hidden_dim)
@@ -417,6 +418,11 @@ class UNetModel(nn.Module):
             raise ValueError("condition has %d rows for a batch of %d (1 or %d expected)" % (condition.shape[0], batch, batch))
         if condition.shape[0] > 1 and condition.stride(0) == 0:
             condition = condition[0].unsqueeze(0)   # one row expanded to the batch (MoleculeGenerator, sample_ddpm_sharded): still one row
+        elif condition.shape[0] > 1 and self.detect_shared_condition and bool((condition == condition[:1]).all()):
+            # opt-in for callers that materialise the repeated row, like the reference's own generator (molecule_generator.py:238-245):
+            # one comparison and one host synchronisation per call; off by default because a data-dependent choice would let a
+            # shard whose rows happen to agree differ in the last bits from the same rows sampled in a mixed batch
+            condition = condition[:1].contiguous()
         return condition
 
     def _initialize_weights(self):
@@ -514,6 +520,7 @@ class DiffusionModel(nn.Module):
             compute_dtype=self.compute_dtype,
             strict_shapes=config.get('strict_shapes', True),
         ).to(self.device)
+        self.model.detect_shared_condition = bool(config.get('detect_shared_condition', False))
 
         # schedule tables: computed on the host with the reference's own expressions (:57-60), then moved
         self.beta_schedule = self._create_beta_schedule()
