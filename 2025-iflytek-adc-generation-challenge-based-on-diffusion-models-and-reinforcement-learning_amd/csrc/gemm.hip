@@ -1528,14 +1528,20 @@ static int launch_w1(const GemmParams& p, hipStream_t stream) {
 // own ring bookkeeping and vmcnt, and the waves meet at ONE barrier per K tile: a loader arrives when its part of tile t has landed,
 // wave 0 when its fragment reads of tile t - 1 have returned, after which the loaders refill the stage of tile t - 1.  Every wave
 // runs exactly nt barriers.  Fragments, K order and epilogue as in the other kernels: bit-identical results.
+constexpr int cl_loaders(int bm, int bn) { return bm == 64 && bn > 32 ? 3 : (bm + bn) / 32; }
+
 template <int BM, int BN>
-__global__ __launch_bounds__(64 * (1 + (BM + BN) / 32)) void gemm_cl_bf16_kernel(const GemmParams p) {
+__global__ __launch_bounds__(64 * (1 + cl_loaders(BM, BN))) void gemm_cl_bf16_kernel(const GemmParams p) {
     typedef bf16_t T;
     constexpr int TM = BM / 16, TN = BN / 16;
     constexpr int AP = BM / 8, WP = BN / 8, P = AP + WP;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
     constexpr int D = 147456 / STAGE_BYTES < 8 ? 147456 / STAGE_BYTES : 8;   // ring stages; a loader has (D - 1) * 4 pieces in flight
+    // groups of four pieces; loader waves: one per group, except for the 64-row tiles wider than 32 columns, whose compute wave needs
+    // more than the 256 registers that five or seven waves would leave it: three loaders there, with one or two groups each
+    constexpr int G = P / 4, NL = cl_loaders(BM, BN);
     constexpr int NM = 2 * TM * TN, NR = 2 * (TM + TN);
+    static_assert(G <= 2 * NL && (D - 1) * 8 <= 63, "loader geometry");
     static_assert(NR <= NM && D >= 3 && D - 2 <= 7 && AP % 4 == 0 && WP % 4 == 0, "ring geometry");
     typedef Epilogue<T, 64, BN, BM, BN, TM, TN> Epi;
     static_assert(D * STAGE_BYTES >= Epi::STAGE_BYTES, "the epilogue stages through the ring's memory");
@@ -1549,6 +1555,7 @@ __global__ __launch_bounds__(64 * (1 + (BM + BN) / 32)) void gemm_cl_bf16_kernel
     const int nt = p.nt_total;
 
     if (wave != 0) {
+      if constexpr (NL == G) {
         // ---- loader: pieces 4 (wave - 1) .. + 3 of every tile, all of them A rows or all of them W rows
         const int first = 4 * (wave - 1);
         const bool loads_a = first < AP;
@@ -1597,6 +1604,75 @@ __global__ __launch_bounds__(64 * (1 + (BM + BN) / 32)) void gemm_cl_bf16_kernel
             stage = stage == D - 1 ? 0 : stage + 1;
         }
         return;
+      } else {
+        // ---- loader: the groups wave - 1, wave - 1 + NL, ... of four pieces each (a group is all A rows or all W rows)
+        const int w = wave - 1;
+        const int ng = (G - w + NL - 1) / NL;   // 1 or 2 groups
+        auto make_srd = [](unsigned long long base, unsigned bytes) {
+            return i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)base), __builtin_amdgcn_readfirstlane((int)((unsigned)(base >> 32) & 0xffffu)),
+                         __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+        };
+        i32x4 srd[2];
+        int voff[2][4];   // lane offsets of a group's four pieces, 1024 j lower for the instruction offset
+        bool is_a[2];
+        int row0[2];      // first row of the group's 32 rows inside its operand's tile
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int first = 4 * (w + gi * NL);
+            is_a[gi] = first < AP;
+            row0[gi] = 8 * (is_a[gi] ? first : first - AP);
+        }
+        auto enter_segment = [&](int gi, int sg) {   // A: K segment sg; W: its single segment
+            const unsigned ld = is_a[gi] ? (unsigned)p.lda[sg] * 2u : (unsigned)p.ldw * 2u;
+            const unsigned long long base = is_a[gi] ? (unsigned long long)p.A[sg] + (unsigned long long)m0 * ld
+                                                     : (unsigned long long)p.W + (unsigned long long)n0 * ld;
+            const int kt = is_a[gi] ? p.ktiles[sg] : nt;
+            srd[gi] = make_srd(base, (unsigned)((is_a[gi] ? BM : BN) - 1) * ld + (unsigned)kt * 128u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = row0[gi] + 8 * j + (lane >> 3);
+                voff[gi][j] = (int)((unsigned)row * ld + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16)) - 1024 * j;
+            }
+        };
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+            if (gi < ng) enter_segment(gi, 0);
+        int seg = 0, tt = 0, it = 0;   // K segment of A, tile inside it, tiles issued
+        auto issue = [&](int stage) {   // the next tile into `stage`
+            if (tt == p.ktiles[seg]) {
+                ++seg; tt = 0;
+                if (tt == p.ktiles[seg]) ++seg;
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi)
+                    if (gi < ng && is_a[gi]) enter_segment(gi, seg);
+            }
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                if (gi < ng) {
+                    const int so = (is_a[gi] ? tt : it) * 128;
+                    const unsigned dst = lds0 + (unsigned)stage * STAGE_BYTES + (unsigned)(w + gi * NL) * 4096u;
+                    const i32x4 sd = {__builtin_amdgcn_readfirstlane(srd[gi][0]), __builtin_amdgcn_readfirstlane(srd[gi][1]),
+                                      __builtin_amdgcn_readfirstlane(srd[gi][2]), 0x00020000};   // wave-uniform: keep it in scalar registers
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dma_piece(j, voff[gi][j], sd, __builtin_amdgcn_readfirstlane(so), __builtin_amdgcn_readfirstlane((int)dst));
+                }
+            }
+            ++tt; ++it;
+        };
+#pragma unroll
+        for (int k = 0; k < D - 1; ++k)
+            if (k < nt) issue(k);
+        int stage = D - 1;
+        for (int t = 0; t < nt; ++t) {
+            const int ahead = (nt < t + D - 1 ? nt : t + D - 1) - (t + 1);
+            if (ng == 2) wait_tiles_in_flight<8>(ahead);
+            else wait_tiles_in_flight<4>(ahead);
+            __builtin_amdgcn_s_barrier();
+            if (t + D - 1 < nt) issue(stage);
+            stage = stage == D - 1 ? 0 : stage + 1;
+        }
+        return;
+      }
     }
 
     // ---- compute wave
@@ -1672,7 +1748,7 @@ static int launch_cl(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     q.ntn = p.N / BN;
     const int row_tiles = (p.m_valid + BM - 1) / BM;
-    hipLaunchKernelGGL((gemm_cl_bf16_kernel<BM, BN>), dim3(row_tiles * q.ntn), dim3(64 * (1 + (BM + BN) / 32)), smem, stream, q);
+    hipLaunchKernelGGL((gemm_cl_bf16_kernel<BM, BN>), dim3(row_tiles * q.ntn), dim3(64 * (1 + cl_loaders(BM, BN))), smem, stream, q);
     return check_launch("gemm (compute wave + loader waves)");
 }
 
@@ -1839,14 +1915,17 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         const bool same_sums = bn != 64 || a.N % 128 == 0;
         const bool take = same_sums && (a.tile_hint != 0 || (w1_default && p.m_valid <= w1_rows && (long)((p.m_valid + 63) / 64) * (a.N / bn) <= 1024));
         // the variant with loader waves where it is the faster one: 32 rows and tiles of 64 or 128 columns (-10 % / -19 % per launch);
-        // with 32 columns it loses, and 64-row tiles wider than 32 columns would spill (more than four waves leave the compute
-        // wave 256 registers).  325 = that variant wherever it exists, 32 = never (measurement aids)
+        // with 32 columns it loses.  325 = that variant wherever it exists, 32 = never (measurement aids)
         static const bool cl_default = [] { const char* e = getenv("ADCDIFF_GEMM_CL"); return e ? atoi(e) != 0 : true; }();
         if (take && a.N % bn == 0) {
             if (a.tile_hint == 325 || (a.tile_hint == 0 && cl_default)) {
                 if (bn == 32 && a.tile_hint == 325) return r32 ? launch_cl<32, 32>(p, stream) : launch_cl<64, 32>(p, stream);
-                if (bn == 64 && r32) return launch_cl<32, 64>(p, stream);
-                if (bn == 128 && r32) return launch_cl<32, 128>(p, stream);   // the two halves of a 128-channel group meet inside a 16-lane row
+                // 64-row tiles: while every workgroup gets a CU of its own (their rings fill a CU's LDS; with 16 row tiles at
+                // batch 1024 the one-wave kernel, two workgroups per CU, is the faster one: 17.7 against 19.8 ms DDIM-50)
+                const bool one_round = a.tile_hint == 325 || (long)((p.m_valid + 63) / 64) * (a.N / bn) <= 256;
+                if (bn == 64 && (r32 || one_round)) return r32 ? launch_cl<32, 64>(p, stream) : launch_cl<64, 64>(p, stream);
+                // the two halves of a 128-channel group meet inside a 16-lane row
+                if (bn == 128 && (r32 || one_round)) return r32 ? launch_cl<32, 128>(p, stream) : launch_cl<64, 128>(p, stream);
             }
             if (bn == 32) return r32 ? launch_w1<32, 32>(p, stream) : launch_w1<64, 32>(p, stream);
             if (bn == 64) return r32 ? launch_w1<32, 64>(p, stream) : launch_w1<64, 64>(p, stream);

@@ -53,7 +53,7 @@ def test_one_wave_kernel_isa(isa, bm, bn):
     assert sum("offen" in ln and ln.endswith("lds") for ln in lines) % pieces == 0   # whole tiles of LDS-DMA pieces only
 
 
-@pytest.mark.parametrize("bm,bn", [(32, 32), (32, 64), (32, 128), (64, 32)])
+@pytest.mark.parametrize("bm,bn", [(32, 32), (32, 64), (32, 128), (64, 32), (64, 64), (64, 128)])
 def test_loader_wave_kernel_isa(isa, bm, bn):
     lines, scratch = _kernel(isa, "_ZN7adcdiff19gemm_cl_bf16_kernelILi%dELi%dEEEvNS_10GemmParamsE" % (bm, bn))
     assert scratch == 0
