@@ -14,7 +14,7 @@ shapes = [(256, [256, 512], 3), (512, [512, 256], 3), (1024, [1024, 512], 3), (2
           (256, [128, 64], 1), (512, [64, 64, 64], 2)]
 bf = torch.bfloat16
 bad = 0
-for M, live in ([(128, 32), (128, 17)] if hint in (32, 325) else [(65536, 0), (4096, 0), (256, 0)]):
+for M, live in ([(128, 32), (128, 17), (128, 64), (256, 200)] if hint in (32, 325) else [(65536, 0), (4096, 0), (256, 0)]):
     for N, Ks, nout in shapes:
         As = [torch.randn(M, k, device="cuda").to(bf) for k in Ks]
         W = (torch.randn(N, sum(Ks), device="cuda") / sum(Ks) ** 0.5).to(bf)
