@@ -25,14 +25,30 @@ import platform
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import adcdiff  # noqa: E402
-from adcdiff import _lib, ops, parallel  # noqa: E402
+# torch, numpy and the package are imported by load_runtime(), in the worker processes only: the process that starts the
+# ranks of a multi-GPU run (launch_ranks) must never initialise a GPU.
+np = torch = adcdiff = _lib = ops = parallel = None
+
+
+def load_runtime(need_library=True):
+    global np, torch, adcdiff, _lib, ops, parallel
+    import numpy as np_
+    import torch as torch_
+    np, torch = np_, torch_
+    if need_library:
+        import adcdiff as adcdiff_
+        from adcdiff import _lib as lib_, ops as ops_, parallel as parallel_
+        adcdiff, _lib, ops, parallel = adcdiff_, lib_, ops_, parallel_
+    else:
+        # the launcher self-test needs the row-sharding helpers only (pure torch.distributed, no native library)
+        import importlib.util
+        pkg = os.path.join(ROOT, "2025-iflytek-adc-generation-challenge-based-on-diffusion-models-and-reinforcement-learning_amd")
+        spec = importlib.util.spec_from_file_location("adcdiff_parallel_only", os.path.join(pkg, "parallel.py"))
+        parallel = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(parallel)
 
 WORKLOADS = {
     # name: (compute dtype, per-GPU batch, description of the configuration)
@@ -41,6 +57,7 @@ WORKLOADS = {
     "shard_1m": ("bf16", 1048576, "configs[3]: 1M samples sharded over the GPUs, RCCL all-gather of latents"),
     "train_dp": ("bf16", 4096, "configs[4]: denoiser train step (q_sample noise-pred loss fwd+bwd), data parallel, batch 4096 per GPU"),
     "bf16_b32": ("bf16", 32, "the generator's own call (molecule_generator.py:238-262): 32 latents per call, bf16"),
+    "launcher_selftest": ("f32", 1000, "rank start-up, row sharding and gather on the CPU (gloo); no GPU work"),
 }
 DIMS = (512, 256, 512)
 ALGO_FLOP_PER_SAMPLE_STEP = 81.92e6     # 2 * 40 960 000 MACs: denoiser linears with the time term hoisted
@@ -185,6 +202,25 @@ def summarize_records(records, dtype, units, algo_flop_per_unit, workload):
     return out
 
 
+def fp32_side_result(dev):
+    """BASELINE configs[1] (the same denoiser in exact float32, batch 4096, T = 1000) beside the default line: one untimed
+    100-step run, then ONE full reverse loop timed between synchronisations, and the live roofline of its GEMMs."""
+    model = build_model("fp32", dev)
+    B = 4096
+    model.p_sample_loop((B, DIMS[2]), None, seed=SEED, t_start=999, t_stop=900)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = model.p_sample_loop((B, DIMS[2]), None, seed=SEED + 1)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    recs, clean_ms, over = timed_window(lambda: model.p_sample_loop((B, DIMS[2]), None, seed=SEED, t_start=999, t_stop=992))
+    roofs = summarize_records(recs, "fp32", B * 8, ALGO_FLOP_PER_SAMPLE_STEP, "fp32_b4096")
+    return {"metric": "DDPM samples/sec (T=1000)", "value": round(B / el, 2), "unit": "samples/s", "dtype": "fp32", "steps": 1,
+            "ms_per_step": round(el * 1e3, 2), "config": {"workload": WORKLOADS["fp32_b4096"][2], "per_gpu_batch": B, "timesteps": 1000},
+            "outputs_finite": bool(torch.isfinite(out).all().item()), "roofline": roofs["roofline"],
+            "roofline_all_gemms": roofs["roofline_all_gemms"]}
+
+
 def cpu_model_name():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -232,6 +268,65 @@ def cpu_baseline(weights, target_seconds=12.0):
                                      "sample": "same, batch 4096, %d steps timed (%.0f ms/step)" % (n4k, ps4k * 1e3)}}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no rendezvous in the environment: start the N ranks as a CHILD process
+    (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) with this command line, pass their output through and
+    return their exit code.  This process has imported neither torch nor the library and never touches a GPU; it is not
+    replaced by the child (no exec)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launcher_selftest(args, rank, world):
+    """The rank plumbing of a multi-GPU run on the CPU (gloo), with no GPU and no native library: every rank fills its row
+    shard with a function of the GLOBAL row index, the shards are gathered as the sampling workloads gather their latents,
+    and the line has the same barrier / max-over-ranks timing.  Not a measurement; tests/test_bench_launcher_cpu.py runs it."""
+    load_runtime(need_library=False)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    total, d = args.batch or 1000, 8
+    first, count = parallel.shard_rows(total, world, rank)
+
+    def one_pass(k):
+        rows = (torch.arange(first, first + count, dtype=torch.float32)[:, None] * d + torch.arange(d, dtype=torch.float32)[None, :]) + k
+        return parallel.gather_rows(rows, total) if world > 1 else rows
+    for k in range(args.warmup):
+        one_pass(-1 - k)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = one_pass(k)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    want = torch.arange(total * d, dtype=torch.float32).reshape(total, d) + (args.steps - 1)
+    ok = bool(out.shape == want.shape and torch.equal(out, want))
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test rows/sec (CPU, gloo; not a measurement)", "value": round(total * args.steps / elapsed, 1),
+                          "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "launcher_selftest", "rows": total},
+                          "ranks": dist.get_world_size() if world > 1 else 1, "gathered_rows_match": ok}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,13 +338,20 @@ def main():
     ap.add_argument("--condition", action="store_true", help="conditional sampling: a one-row condition repeated to the batch")
     ap.add_argument("--sampler", choices=["ddpm", "ddim50"], default="ddpm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="default workload only: skip the float32 batch-4096 (configs[1]) side result")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the two must agree (run `python bench.py --gpus N`, which starts its own "
+                         "ranks, or torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    if args.workload == "launcher_selftest":
+        return launcher_selftest(args, rank, world)
+    load_runtime()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -305,6 +407,33 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     finite = bool(np.isfinite(out["loss"])) if training else bool(torch.isfinite(out).all().item())
+    collective = None
+    if world > 1:
+        # the job's one exchange, timed alone on every rank (max over ranks): the all-gather of the latents or the all-reduce
+        # of the gradient arena; it is inside `elapsed` above as well
+        if training:
+            flat = model.model.grad_arena_if_aliased()
+            fn_c = (lambda: parallel.allreduce_gradients(model.model.parameters(), flat=flat)) if flat is not None else None
+            nbytes = flat.numel() * 4 if flat is not None else 0
+            name = "RCCL all-reduce of the float32 gradient arena"
+        else:
+            local = out[first:first + count].contiguous()
+            fn_c = lambda: parallel.gather_rows(local, total)
+            nbytes, name = total * DIMS[2] * 4, "RCCL all-gather of the [global_batch, 512] float32 latents"
+        if fn_c is not None:
+            fn_c()
+            dist.barrier()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn_c()
+            e1.record()
+            torch.cuda.synchronize()
+            tc = torch.tensor([e0.elapsed_time(e1) / 3], device=dev, dtype=torch.float64)
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            collective = {"what": name, "ms": round(float(tc.item()), 4), "bytes_result_per_rank": nbytes,
+                          "share_of_step": round(float(tc.item()) * 1e-3 / (elapsed / args.steps), 5)}
 
     if rank == 0:
         # live roofline: per-launch events over a short window of the same work
@@ -322,8 +451,9 @@ def main():
             else:
                 fn = lambda: model.p_sample_loop((wb, DIMS[2]), cond, seed=SEED, row_offset=first, t_start=999, t_stop=1000 - window)
             recs, clean_ms, over = timed_window(fn)
-            roofs = summarize_records(recs, dtype, wb * window, ALGO_FLOP_PER_SAMPLE_STEP_COND if args.condition else ALGO_FLOP_PER_SAMPLE_STEP,
-                                      args.workload)
+            # --condition passes ONE condition row for the batch (the generator's call): its time projection is a row bias, the
+            # step executes the unconditional 81.92 MFLOP and is credited with that; 87.03 applies to B distinct condition rows
+            roofs = summarize_records(recs, dtype, wb * window, ALGO_FLOP_PER_SAMPLE_STEP, args.workload)
             nsteps = 50 if args.sampler == "ddim50" else T
             samples = total * args.steps * (1.0 if args.sampler == "ddim50" else T / 1000.0)
             metric = "DDPM samples/sec (T=1000)" if args.sampler == "ddpm" else "DDIM-50 samples/sec"
@@ -340,8 +470,10 @@ def main():
                        "parallelism": ("rows sharded over %d GPU(s), RCCL all-gather of latents" % world) if not training else
                                       ("data parallel over %d GPU(s), RCCL all-reduce of the gradient arena" % world),
                        "weights": "random (counter RNG, xavier variance), no checkpoint ships"},
-            "outputs_finite": finite,
+            "outputs_finite": finite, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
         }
+        if collective:
+            line["collective"] = collective
         line.update(roofs)
         if per_unit_ms is not None:
             line["ms_per_denoise_step"] = per_unit_ms
@@ -349,11 +481,14 @@ def main():
             line["cpu_baseline"] = cpu_baseline({k: v.detach().cpu().numpy() for k, v in model.model.state_dict().items()})
             if args.sampler == "ddpm":
                 line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+        if world == 1 and args.workload == "bf16_b65536" and not args.condition and args.sampler == "ddpm" and T == 1000 and not args.no_fp32:
+            line["configs_1_fp32_b4096"] = fp32_side_result(dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
