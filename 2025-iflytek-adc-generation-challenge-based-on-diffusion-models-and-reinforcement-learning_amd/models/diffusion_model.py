@@ -322,22 +322,26 @@ class _NoisePredictionLoss(torch.autograd.Function):
                 off += (p.numel() + 3) // 4 * 4
         flat.zero_()                         # bias / GroupNorm gradients are accumulated with atomics
         grads = _lib.UnetGrads()
-        by_param = {}
         for (p, path), g in zip(slots, views):
-            by_param[id(p)] = g
             target = grads if len(path) == 1 else grads.blocks[path[0]]
             setattr(target, path[-1], g.data_ptr())
         table = torch.frombuffer(bytearray(bytes(grads)), dtype=torch.int64)     # the adcdiff_unet_grads struct as a CPU tensor
-        torch.ops.adcdiff.unet_backward(ctx.handle.value, ctx.d_eps, table, flat, ctx.ws_tensor)
+        # d(loss * c) = c * d(loss): the backward pass is linear in d(eps), so the factor goes onto that [B, D] tensor
+        # (a few MB) instead of a pass over the whole gradient arena; no host synchronisation
+        d_eps = ctx.d_eps * grad_out.to(ctx.d_eps.dtype)
+        torch.ops.adcdiff.unet_backward(ctx.handle.value, d_eps, table, flat, ctx.ws_tensor)
         eng.generation += 1                  # the tape is consumed
-        flat.mul_(grad_out)                  # d(loss * c) = c * d(loss): one pass over the arena, no host sync
-        out = []
-        for p in params:
-            g = by_param.get(id(p))
-            if g is not None and p.grad is None and p.requires_grad:
-                p.grad = g                   # the arena view IS the gradient: nothing is allocated or copied per step
-                g = None
-            out.append(g)
+        # The gradients are RETURNED to autograd (its AccumulateGrad nodes install or add them, tensor hooks and
+        # post-accumulate hooks fire, torch.autograd.grad() gets them).  train_step opts into aliasing: it hands out fresh
+        # views of the persistent arena, which autograd adopts as .grad without a copy, so the all-reduce and the fused
+        # optimizer work on one flat buffer -- such .grad tensors are overwritten by the next backward.  Every other caller
+        # of p_losses gets views of a private copy that nothing overwrites.
+        src = flat if model.alias_gradients else flat.clone()
+        fresh, off = {}, 0
+        for p, _ in slots:
+            fresh[id(p)] = src[off:off + p.numel()].view_as(p)
+            off += (p.numel() + 3) // 4 * 4
+        out = [fresh.get(id(p)) if p.requires_grad else None for p in params]
         return (None, None, None, None, None, None) + tuple(out)
 
 
@@ -381,6 +385,10 @@ class UNetModel(nn.Module):
         self._initialize_weights()
         self._engines = {}
         self._grad_flat = None
+        # True (train_step sets it around its backward; a caller may too): backward hands out views of ONE persistent flat
+        # gradient buffer, so nothing is copied per step and a data-parallel all-reduce takes one collective -- but those
+        # .grad tensors are overwritten by the next backward.  False: every backward returns gradients nothing overwrites.
+        self.alias_gradients = False
 
     def _grad_arena(self, slots):
         """One persistent flat float32 buffer with a 16-byte aligned view per parameter gradient (allocated once)."""
@@ -799,9 +807,13 @@ class DiffusionModel(nn.Module):
         # data parallel: every rank draws the timesteps of the global batch and keeps its own slice, and the forward-diffusion
         # noise is keyed by global row, so ranks seeded alike train on independent samples (one process: the plain draw)
         t = torch.randint(0, self.num_timesteps, (world * batch_size,), device=self.device)[rank * batch_size:(rank + 1) * batch_size]
-        loss = self.p_losses(x, t, row_offset=rank * batch_size)
-        loss = loss / self.gradient_accumulation_steps
-        loss.backward()
+        alias_before, self.model.alias_gradients = self.model.alias_gradients, True   # .grad = views of the persistent arena
+        try:
+            loss = self.p_losses(x, t, row_offset=rank * batch_size)
+            loss = loss / self.gradient_accumulation_steps
+            loss.backward()
+        finally:
+            self.model.alias_gradients = alias_before
         if (step + 1) % self.gradient_accumulation_steps == 0:
             # data parallel (one process per GPU): average the gradients over the ranks before clipping, so that the
             # clipped norm and the AdamW step are identical on every rank; a no-op in a single process

@@ -44,7 +44,7 @@ def row_scaled_err(a, b):
 
 
 # Gates on the final latents of a reverse loop, about 3x what was observed on an MI355X for {tiny, Config A, Config B} x
-# {DDPM 1000, DDIM 50} (profiles/parity_r02.json, written by tests/parity_report.py; observed maxima in brackets):
+# {DDPM 1000, DDIM 50} (profiles/parity_r02.json, written by tools/parity_report.py; observed maxima in brackets):
 #   elem_max / elem_p999: |d_ij| / max(1, |ref_ij|)       fp32 [1.9e-4 / 1.2e-4]   bf16 [1.63 / 0.88]
 #   row_scaled:           |d_ij| / max(1, rms of ref row)  fp32 [2.0e-5]            bf16 [1.1e-2]
 # The latents grow to |x| ~ 180 (median) .. 990 (max) with random weights, and the bf16-operand path carries an ABSOLUTE error

@@ -334,6 +334,7 @@ def test_gradient_accumulation_keeps_earlier_gradients():
     persistent gradient arena (which the first pass's .grad tensors alias)."""
     m = build("fp32")
     m.model.eval()
+    m.model.alias_gradients = True                   # as inside train_step
     x, t = cu(philox.normal(SEED, 52, 0, 0, 16, 128)), torch.arange(16, device="cuda") * 50
     nz = cu(philox.normal(SEED, 53, 0, 0, 16, 128))
     m.p_losses(x[:8], t[:8], noise=nz[:8]).backward()
@@ -348,6 +349,40 @@ def test_gradient_accumulation_keeps_earlier_gradients():
     for k, p in m.model.named_parameters():
         if p.grad is not None:
             assert torch.allclose(total[k], ga[k] + p.grad, rtol=0, atol=1e-6 * max(1.0, float(total[k].abs().max()))), k
+
+
+def test_public_p_losses_honours_the_autograd_contract():
+    """Outside train_step the gradients are ordinary autograd results: torch.autograd.grad returns them, tensor hooks and
+    post-accumulate hooks fire on the first backward, and a .grad kept across steps is not overwritten by the next one."""
+    m = build("fp32")
+    m.model.eval()
+    x, t = cu(philox.normal(SEED, 52, 0, 0, 16, 128)), torch.arange(16, device="cuda") * 50
+    nz = cu(philox.normal(SEED, 53, 0, 0, 16, 128))
+    w = m.model.middle[0].linear1.weight
+    seen = []
+    h1 = w.register_hook(lambda g: seen.append(("tensor", float(g.abs().sum()))))
+    h2 = w.register_post_accumulate_grad_hook(lambda p: seen.append(("post", float(p.grad.abs().sum()))))
+    m.p_losses(x[:8], t[:8], noise=nz[:8]).backward()
+    assert [k for k, _ in seen] == ["tensor", "post"] and seen[0][1] > 0 and seen[0][1] == seen[1][1]
+    h1.remove(); h2.remove()
+    kept = w.grad
+    snapshot = kept.clone()
+    assert m.model.grad_arena_if_aliased() is None
+    m.model.zero_grad(set_to_none=True)
+    params = [p for p in m.model.parameters() if p.requires_grad]
+    got = torch.autograd.grad(m.p_losses(x[8:], t[8:], noise=nz[8:]), params, allow_unused=True)
+    assert all(p.grad is None for p in params)                      # autograd.grad does not write .grad
+    assert torch.equal(kept, snapshot)                              # the earlier step's gradient tensor is untouched
+    have = [g for g in got if g is not None]
+    assert len(have) >= 100 and all(torch.isfinite(g).all() for g in have)
+    m.p_losses(x[8:], t[8:], noise=nz[8:]).backward()
+    for p, g in zip(params, got):
+        if g is not None:
+            assert torch.equal(p.grad, g)
+    # a scaled loss scales the gradients (the factor is applied to d(eps) before the backward kernels)
+    m.model.zero_grad(set_to_none=True)
+    (m.p_losses(x[8:], t[8:], noise=nz[8:]) * 0.25).backward()
+    assert torch.allclose(w.grad, 0.25 * got[params.index(w)], rtol=1e-5, atol=1e-9)
 
 
 def test_validation_loss_follows_training_mode():
@@ -377,6 +412,7 @@ def _dp_worker(rank, world, port, out_dir):
         g = load_golden("tiny")
         m = build("fp32", use_mixed_precision=False)
         m.model.eval()
+        m.model.alias_gradients = True
         lo, hi = rank * 4, rank * 4 + 4
         nz = cu(philox.normal(SEED, philox.STREAM_QNOISE, 0, 0, 8, 128))
         m.p_losses(cu(g["train_x0"])[lo:hi], cu(g["train_t"], torch.int64)[lo:hi], noise=nz[lo:hi]).backward()

@@ -1,5 +1,5 @@
 """Manual A/B of two builds of the library on GEMM shapes, interleaved rounds in one process:
-python tests/gemm_ab.py libA.so libB.so [hint]   (prints median microseconds per shape and build)."""
+python tools/gemm_ab.py libA.so libB.so [hint]   (prints median microseconds per shape and build)."""
 import statistics
 import sys
 import torch

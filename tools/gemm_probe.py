@@ -1,4 +1,4 @@
-"""Manual probe of one GEMM shape: python tests/gemm_probe.py N K1[,K2..] nout hint iters  (nout: -1 = operand-type output only)."""
+"""Manual probe of one GEMM shape: python tools/gemm_probe.py N K1[,K2..] nout hint iters  (nout: -1 = operand-type output only)."""
 import sys
 import torch
 sys.path.insert(0, ".")

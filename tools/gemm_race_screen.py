@@ -1,4 +1,4 @@
-"""Manual race screen for a GEMM kernel variant: python tests/gemm_race_screen.py HINT [iters]
+"""Manual race screen for a GEMM kernel variant: python tools/gemm_race_screen.py HINT [iters]
 Runs every layer shape `iters` times and compares each run's outputs bit for bit with the single-stage 128-row kernel's.
 HINT 32 (the one-wave kernel) runs 128 padded rows with 32 and 17 live ones and compares the live rows."""
 import sys

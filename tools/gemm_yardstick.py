@@ -1,7 +1,7 @@
 """Manual yardstick: the library GEMM (torch.matmul -> hipBLASLt/rocBLAS, bf16) on the denoiser's shapes next to adcdiff_gemm with
 a bare epilogue (one operand-type output), on random and on zero operands.  Says how far the hand-written main loop is from what
 the vendor library reaches on the same chip under the same clocks; it is not a parity test.
-    python tests/gemm_yardstick.py [M] [iters]"""
+    python tools/gemm_yardstick.py [M] [iters]"""
 import sys
 import torch
 sys.path.insert(0, ".")

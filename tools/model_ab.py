@@ -1,5 +1,5 @@
 """Manual A/B of two builds of the library on the whole denoising step (bf16, batch 65536), interleaved rounds in one
-process: python tests/model_ab.py libA.so libB.so"""
+process: python tools/model_ab.py libA.so libB.so"""
 import statistics
 import sys
 import time

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Observed parity of the GPU path against the reference's golden vectors, as numbers (run on the GPU box):
 
-    python tests/parity_report.py gpurun_out/parity.json
+    python tools/parity_report.py gpurun_out/parity.json
 
 For {tiny 128/128/128, Config A 512/256/512, Config B 512/128/512} x {fp32, bf16} x {DDPM T = 1000, DDIM 50 steps}
 the final latents of the drop-in class (in-kernel Philox noise) against what the reference computed with the same noise

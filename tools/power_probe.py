@@ -1,5 +1,5 @@
 """Manual: board power and shader clock while one GEMM variant runs back to back for a few seconds.
-    python tests/power_probe.py own|lib rand|zero [N K hint]"""
+    python tools/power_probe.py own|lib rand|zero [N K hint]"""
 import subprocess
 import sys
 import threading

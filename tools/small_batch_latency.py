@@ -1,4 +1,4 @@
-"""Wall time of the generator's real call at its default batch: python tests/small_batch_latency.py [BATCH] [DTYPE]
+"""Wall time of the generator's real call at its default batch: python tools/small_batch_latency.py [BATCH] [DTYPE]
 
 MoleculeGenerator.generate_molecules samples 32 latents per call with DDIM-50 and a one-row condition
 (molecule_generator.py:238-262).  Prints one JSON line with the median wall time of sample() for DDIM-50 and DDPM-1000,

@@ -1,4 +1,4 @@
-"""Manual per-launch breakdown of one denoising step: python tests/step_breakdown.py DTYPE BATCH"""
+"""Manual per-launch breakdown of one denoising step: python tools/step_breakdown.py DTYPE BATCH"""
 import sys
 import torch
 sys.path.insert(0, ".")
