@@ -122,6 +122,8 @@ SIGNATURES = {
     "adcdiff_clip_adamw_workspace_bytes": (C.c_size_t, [C.c_longlong]),
     "adcdiff_clip_adamw_step": (C.c_int, [c_fp, C.c_int, C.c_longlong, C.POINTER(AdamWArgs), c_fp, c_fp, C.c_size_t, c_fp]),
     "adcdiff_clip_adamw_step_noalloc": (C.c_int, [c_fp, C.c_int, C.c_longlong, C.POINTER(AdamWArgs), c_fp, c_fp]),
+    "adcdiff_debug_set": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "adcdiff_debug_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
     "adcdiff_timing_begin": (C.c_int, [C.c_int]),
     "adcdiff_timing_end": (C.c_int, [C.POINTER(TimingRecord), C.c_int, C.POINTER(C.c_int)]),
 }
@@ -146,8 +148,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.adcdiff_abi_version() != 2:
-        raise AdcdiffError("libadcdiff.so has ABI version %d, expected 2" % lib.adcdiff_abi_version())
+    if lib.adcdiff_abi_version() != 3:
+        raise AdcdiffError("libadcdiff.so has ABI version %d, expected 3" % lib.adcdiff_abi_version())
     _lib = lib
     return lib
 
@@ -155,3 +157,14 @@ def load():
 def check(rc):
     if rc != 0:
         raise AdcdiffError("adcdiff error %d: %s" % (rc, load().adcdiff_last_error().decode("utf-8", "replace")))
+
+
+def debug_set(key, value):
+    """A measurement / test switch of the library (adcdiff_debug_set); process-wide."""
+    check(load().adcdiff_debug_set(key.encode(), int(value)))
+
+
+def debug_get(key):
+    v = C.c_longlong()
+    check(load().adcdiff_debug_get(key.encode(), C.byref(v)))
+    return int(v.value)

@@ -2,7 +2,9 @@
 // variance, Philox noise), DDIM update, q_sample, Philox fill, and the small table helpers.
 // Built with -ffp-contract=off so that the update formulas round exactly like the reference's
 // separate float32 torch ops.
+#include <atomic>
 #include <cmath>
+#include <cstring>
 #include <mutex>
 
 #include "unet_plan.h"
@@ -374,6 +376,64 @@ int add_vec(const float* a, const float* b, float* out, int n, hipStream_t strea
 }  // namespace adcdiff
 
 using namespace adcdiff;
+
+namespace adcdiff {
+namespace {
+struct DebugEntry { const char* name; long long def; };
+const DebugEntry kDebug[DBG_NKEYS] = {
+    {"tile_hints", 0},        // 1: adcdiff_gemm_args.tile_hint is honoured (0: a non-zero hint is rejected)
+    {"gemm_tile", 0},         // 128 / 256 / 2561: force that tile kernel for every bf16 launch the shape allows
+    {"gemm_ring", 0},         // 1: the ring main loop of the eight-wave 256-tile kernel
+    {"gemm_ring2", 1},        // 0: never the two-stage ring of the 128-row kernels
+    {"gemm_ring_max", 512},   // launches with at most this many 128-row workgroups take a ring of LDS stages
+    {"gemm_w4", 1},           // 0: the eight-wave kernel instead of the four-wave 256-tile kernel
+    {"gemm_w1", 1},           // 0: the tile kernels instead of the one-wave kernels for few live rows
+    {"gemm_w1_rows", 1024},   // live rows up to which the one-wave kernels are taken
+    {"gemm_cl", 1},           // 0: never the loader-wave variant of the one-wave kernel
+    {"step_fold", 1},         // 0: the reverse step as a launch of its own instead of the output GEMM's epilogue
+    {"train_transpose", 0},   // 1: backward products on transposed copies (the NT kernel) instead of gemm_tr
+    {"sync", 0},              // 1: synchronise and check after every training launch
+    {"raster", 0},            // workgroup -> tile order of the four-wave kernel (0 = shipped)
+};
+std::atomic<long long> g_debug[DBG_NKEYS];
+std::atomic<bool> g_debug_init{false};
+void debug_init() {
+    if (g_debug_init.load(std::memory_order_acquire)) return;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (g_debug_init.load(std::memory_order_relaxed)) return;
+    for (int i = 0; i < DBG_NKEYS; ++i) g_debug[i].store(kDebug[i].def, std::memory_order_relaxed);
+    g_debug_init.store(true, std::memory_order_release);
+}
+}  // namespace
+long long debug_value(int key) {
+    debug_init();
+    return g_debug[key].load(std::memory_order_relaxed);
+}
+}  // namespace adcdiff
+
+extern "C" int adcdiff_debug_set(const char* key, long long value) {
+    using namespace adcdiff;
+    if (!key) return fail(ADCDIFF_E_BADARG, "debug_set: null key");
+    debug_init();
+    for (int i = 0; i < DBG_NKEYS; ++i)
+        if (strcmp(key, kDebug[i].name) == 0) {
+            g_debug[i].store(value, std::memory_order_relaxed);
+            return ADCDIFF_OK;
+        }
+    return fail(ADCDIFF_E_BADARG, "debug_set: unknown key '%s'", key);
+}
+extern "C" int adcdiff_debug_get(const char* key, long long* value) {
+    using namespace adcdiff;
+    if (!key || !value) return fail(ADCDIFF_E_BADARG, "debug_get: null argument");
+    debug_init();
+    for (int i = 0; i < DBG_NKEYS; ++i)
+        if (strcmp(key, kDebug[i].name) == 0) {
+            *value = g_debug[i].load(std::memory_order_relaxed);
+            return ADCDIFF_OK;
+        }
+    return fail(ADCDIFF_E_BADARG, "debug_get: unknown key '%s'", key);
+}
 
 extern "C" int adcdiff_abi_version(void) { return ADCDIFF_ABI_VERSION; }
 extern "C" const char* adcdiff_last_error(void) { return error_buffer(); }

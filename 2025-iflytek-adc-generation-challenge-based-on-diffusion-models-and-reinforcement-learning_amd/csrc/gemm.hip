@@ -1774,13 +1774,15 @@ static int launch_any(const GemmParams& p, bool ring, hipStream_t stream) {
     // of two tiles the per-tile barrier and LDS-DMA issue are the critical path, not the load latency
     // more workgroups than CUs (fp32 batch 4096: 512 tiles of 128 x 128): two stages of 32 KiB let two workgroups share a CU,
     // and one computes while the other waits at its barrier: +8 % samples/s over three stages with one workgroup per CU
-    static const bool two_ok = [] { const char* e = getenv("ADCDIFF_GEMM_RING2"); return e ? atoi(e) != 0 : true; }();   // measurement aid
+    const bool two_ok = debug_value(DBG_GEMM_RING2) != 0;
     if (ring && two_ok && BM == 128 && BN == 128 && (long)(p.M / BM) * (p.N / BN) * p.ksplit > 256) return launch<T, BM, BN, 2>(p, stream);
     return ring ? launch<T, BM, BN, 3>(p, stream) : launch<T, BM, BN, 1>(p, stream);
 }
 
 int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     if (a.dtype != ADCDIFF_F32 && a.dtype != ADCDIFF_BF16) return fail(ADCDIFF_E_BADARG, "gemm: unknown dtype %d", a.dtype);
+    if (a.tile_hint != 0 && debug_value(DBG_TILE_HINTS) == 0)
+        return fail(ADCDIFF_E_BADARG, "gemm: tile_hint=%d: kernel selection by hint is a measurement aid, enable it with adcdiff_debug_set(\"tile_hints\", 1)", a.tile_hint);
     const int esize = a.dtype == ADCDIFF_BF16 ? 2 : 4;
     const int bk = 128 / esize;
     if (a.M <= 0 || a.N <= 0 || a.M % 128 != 0 || a.N % 64 != 0)
@@ -1860,11 +1862,11 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     // shape with at least eight K tiles, by up to 27 % on the 256-wide layers; the 128-row kernel (3-4 workgroups per CU)
     // keeps the K = 256 layers and everything with too few 256-tiles to fill the chip.
     bool big = false, pipelined = false;
-    // measurement aid: ADCDIFF_GEMM_RING=1 selects the ring main loop for every 256-tile launch (tile_hint 2561 does per call);
-    // the two-group phased loop is the default: same cycles per tile within 1 %, but the chip holds a higher clock on it
-    static const bool pipe_default = [] { const char* e = getenv("ADCDIFF_GEMM_RING"); return e ? atoi(e) != 0 : false; }();
+    // the two-group phased loop is the default of the eight-wave kernel: same cycles per tile as the ring loop within 1 %, but
+    // the chip holds a higher clock on it (debug switch gemm_ring / tile_hint 2561 select the ring loop)
+    const bool pipe_default = debug_value(DBG_GEMM_RING) != 0;
     if (a.dtype == ADCDIFF_BF16 && a.M % 256 == 0 && a.N % 256 == 0 && a.tile_hint != 128) {
-        static const int forced = [] { const char* e = getenv("ADCDIFF_GEMM_TILE"); return e ? atoi(e) : 0; }();   // measurement aid
+        const int forced = (int)debug_value(DBG_GEMM_TILE);
         const bool enough_tiles = forced != 128 && (long)(a.M / 256) * (a.N / 256) * p.ksplit >= 192;
         const bool long_k = kslice >= 512;
         big = forced == 256 || forced == 2561 || a.tile_hint == 256 || a.tile_hint == 2561 || a.tile_hint == 2560 || (a.tile_hint >= 2564 && a.tile_hint <= 2568) || (enough_tiles && long_k);
@@ -1881,9 +1883,9 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     bool mid = few && !small && wide;
     for (int g = 0; g < a.n_gn; ++g) mid = mid && a.gn[g].group_size <= 64;
     // big: the 4-wave kernel with the assembly main loop unless the launch splits K, has a single K tile, is one tile wide (the
-    // 8-wave kernel's epilogue is the faster one there and the main loop is short), or a hint / the measurement aid
-    // ADCDIFF_GEMM_W4=0 asks for one of the 8-wave kernels
-    static const bool w4_default = [] { const char* e = getenv("ADCDIFF_GEMM_W4"); return e ? atoi(e) != 0 : true; }();
+    // 8-wave kernel's epilogue is the faster one there and the main loop is short), or a hint / the debug switch gemm_w4 = 0
+    // asks for one of the 8-wave kernels
+    const bool w4_default = debug_value(DBG_GEMM_W4) != 0;
     const bool w4_hint = a.tile_hint == 2564 || a.tile_hint == 2565 || a.tile_hint == 2566 || a.tile_hint == 2568;
     const bool w4 = big && p.ksplit == 1 && p.nt_total >= 2 &&
                     (w4_hint || (w4_default && a.N >= 512 && a.tile_hint != 2560 && a.tile_hint != 2561 && a.tile_hint != 256));
@@ -1898,10 +1900,10 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     }
     // few live rows (the generator's default batch is 32): the one-wave kernel, 32 or 64 rows and 32 columns per workgroup
     // where every GroupNorm group fits in 32, else 64 or 128 (a batch-32 sampling run takes 24 % less time than on the tile kernels); tile_hint 32
-    // asks for it, any other hint (or the measurement aid ADCDIFF_GEMM_W1=0) for the tile kernels
-    static const bool w1_default = [] { const char* e = getenv("ADCDIFF_GEMM_W1"); return e ? atoi(e) != 0 : true; }();
+    // asks for it, any other hint (or the debug switch gemm_w1 = 0) for the tile kernels
+    const bool w1_default = debug_value(DBG_GEMM_W1) != 0;
     // up to 1024 rows (16 row tiles of 64): 12 % less time per sampling step than the 128-row tile kernels at batches of 128 to 1024
-    static const int w1_rows = [] { const char* e = getenv("ADCDIFF_GEMM_W1_ROWS"); return e ? atoi(e) : 1024; }();   // measurement aid
+    const int w1_rows = (int)debug_value(DBG_GEMM_W1_ROWS);
     if (a.dtype == ADCDIFF_BF16 && p.m_valid >= 1 && p.ksplit == 1 && (a.tile_hint == 0 || a.tile_hint == 32 || a.tile_hint == 325)) {
         int gmax = 0;
         for (int g = 0; g < a.n_gn; ++g) gmax = a.gn[g].group_size > gmax ? a.gn[g].group_size : gmax;
@@ -1916,7 +1918,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         const bool take = same_sums && (a.tile_hint != 0 || (w1_default && p.m_valid <= w1_rows && (long)((p.m_valid + 63) / 64) * (a.N / bn) <= 1024));
         // the variant with loader waves where it is the faster one: 32 rows and tiles of 64 or 128 columns (-10 % / -19 % per launch);
         // with 32 columns it loses.  325 = that variant wherever it exists, 32 = never (measurement aids)
-        static const bool cl_default = [] { const char* e = getenv("ADCDIFF_GEMM_CL"); return e ? atoi(e) != 0 : true; }();
+        const bool cl_default = debug_value(DBG_GEMM_CL) != 0;
         if (take && a.N % bn == 0) {
             if (a.tile_hint == 325 || (a.tile_hint == 0 && cl_default)) {
                 if (bn == 32 && a.tile_hint == 325) return r32 ? launch_cl<32, 32>(p, stream) : launch_cl<64, 32>(p, stream);
@@ -1935,7 +1937,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     // few workgroups: nothing else on the CU hides a tile's load latency, so take the three-stage ring
     const int bn = small ? 64 : wide ? 128 : 64, bm = small || mid ? 64 : 128;
     const long blocks = (long)(a.M / bm) * (a.N / bn) * p.ksplit;
-    static const long ring_max = [] { const char* e = getenv("ADCDIFF_GEMM_RING_MAX"); return e ? atol(e) : 512L; }();   // measurement aid
+    const long ring_max = (long)debug_value(DBG_GEMM_RING_MAX);
     const bool ring = a.tile_hint == 3 || (a.tile_hint != 1 && blocks <= ring_max);
     if (a.dtype == ADCDIFF_BF16) {
         if (small) return launch_any<bf16_t, 64, 64>(p, ring, stream);

@@ -191,7 +191,7 @@ int gemm_tr(bool ta, const void* A, long lda, const void* B, long ldb, float* C,
     p.c_slice = slices > 1 ? c_slice : 0;
     const dim3 grid((unsigned)((M / 128) * p.ntn), (unsigned)slices);
     TimingScope ts(ADCDIFF_KIND_GEMM_BF16, M, N, K, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N * slices, stream);
-    static const bool two_ok = [] { const char* e = getenv("ADCDIFF_GEMM_RING2"); return e ? atoi(e) != 0 : true; }();   // measurement aid
+    const bool two_ok = debug_value(DBG_GEMM_RING2) != 0;
     const bool two = two_ok && (long)grid.x * grid.y > 256;
     int rc;
     if (two) rc = ta ? launch_tr<true, 2>(p, grid, stream) : launch_tr<false, 2>(p, grid, stream);

@@ -361,11 +361,8 @@ static int gemm_dw_direct(const void* dY, long ldy, const void* X, long ldx, int
     return check_launch("sum_partials");
 }
 
-// measurement aid: ADCDIFF_TRAIN_TRANSPOSE=1 keeps the backward pass on the NT kernel with transposed copies
-static bool direct_enabled() {
-    const char* e = getenv("ADCDIFF_TRAIN_TRANSPOSE");   // read per call: a test switches it between two backward passes
-    return !(e && atoi(e) != 0);
-}
+// debug switch train_transpose = 1 keeps the backward pass on the NT kernel with transposed copies (a test compares the two)
+static bool direct_enabled() { return debug_value(DBG_TRAIN_TRANSPOSE) == 0; }
 
 static int copy_f32(const float* src, float* dst, long n, int accumulate, hipStream_t st) {
     TimingScope ts(ADCDIFF_KIND_OTHER, 1, 0, 0, 0.0, (double)n * 8.0, st);
@@ -439,11 +436,8 @@ extern "C" int adcdiff_unet_backward(adcdiff_unet* n, const float* d_eps, int ld
     return rc;
 }
 
-// ADCDIFF_DEBUG_SYNC=1 synchronises after every backward launch and names the first one that fails.
-static bool debug_sync() {
-    static const bool on = [] { const char* e = getenv("ADCDIFF_DEBUG_SYNC"); return e && e[0] == '1'; }();
-    return on;
-}
+// debug switch sync = 1 synchronises after every backward launch and names the first one that fails.
+static bool debug_sync() { return debug_value(DBG_SYNC) != 0; }
 #define RUN(expr)                                                                                              \
     do {                                                                                                       \
         if (!dry) {                                                                                            \

@@ -115,7 +115,7 @@ extern "C" int adcdiff_unet_create(const adcdiff_unet_params* p, int dtype, void
     }
     // the packing entries: every weight cast into the concatenated operand layouts, every bias sum, the stacked time_proj copies
     {
-        PackItem items[PACK_MAX_ITEMS];
+        PackItem* const items = n->pack_host;
         int k = 0;
         long long chunks = 0;
         auto add_item = [&](const float* src, const float* add, void* dst, int rows, int cols, int ldd, int col0, int dt) {
@@ -142,10 +142,7 @@ extern "C" int adcdiff_unet_create(const adcdiff_unet_params* p, int dtype, void
         add_item(p->cond0_w, nullptr, n->w_c0, H, n->D, n->D, 0, dtype);
         add_item(p->cond2_w, nullptr, n->w_c2, H, H, H, 0, dtype);
         n->n_pack = k; n->pack_chunks = chunks;
-        if (hipMemcpy(n->pack_table, items, (size_t)k * sizeof(PackItem), hipMemcpyHostToDevice) != hipSuccess) {
-            delete n;
-            return fail(ADCDIFF_E_LAUNCH, "unet_create: copying the packing table into the arena failed (is the arena device memory?)");
-        }
+        n->pack_uploaded = false;   // create copies and launches nothing: the first adcdiff_unet_pack uploads the entries on its stream
     }
     n->packed = false;
     n->sin_built = false;
@@ -168,6 +165,12 @@ extern "C" int adcdiff_unet_pack(adcdiff_unet* n, void* workspace, size_t worksp
     hipStream_t st = as_stream(stream_);
     const adcdiff_unet_params& p = n->prm;
     const int H = n->H;
+    if (!n->pack_uploaded) {
+        // stream-ordered copy out of the plan's own host memory (pageable: the runtime stages it before returning)
+        if (hipMemcpyAsync(n->pack_table, n->pack_host, (size_t)n->n_pack * sizeof(PackItem), hipMemcpyHostToDevice, st) != hipSuccess)
+            return fail(ADCDIFF_E_LAUNCH, "unet_pack: copying the packing table into the arena failed (is the arena device memory?)");
+        n->pack_uploaded = true;
+    }
     TRY(pack_items(n->pack_table, n->n_pack, n->pack_chunks, st));
 
     // TimeEmbedding(t) for every timestep (diffusion_model.py:802-823), float32 throughout
@@ -430,11 +433,8 @@ int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t
     return ADCDIFF_OK;
 }
 
-// measurement aid: ADCDIFF_NO_FOLD=1 keeps the sampler's update and encoder.0's GroupNorm as launches of their own
-bool fold_enabled() {
-    static const bool on = [] { const char* e = getenv("ADCDIFF_NO_FOLD"); return !(e && atoi(e) != 0); }();
-    return on;
-}
+// debug switch step_fold = 0 keeps the sampler's update and encoder.0's GroupNorm as launches of their own
+bool fold_enabled() { return debug_value(DBG_STEP_FOLD) != 0; }
 
 int forward_impl(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform, const float* cemb,
                  int ldce, float* eps, int lde, Bump& ws, bool dry, hipStream_t st) {

@@ -99,6 +99,8 @@ struct adcdiff_unet {
     adcdiff::PackItem* pack_table;      // device copy of the packing entries (in the arena), n_pack entries, pack_chunks chunks
     int n_pack;
     long long pack_chunks;
+    adcdiff::PackItem pack_host[adcdiff::PACK_MAX_ITEMS];   // the entries on the host: adcdiff_unet_pack uploads them on its stream (the first time)
+    bool pack_uploaded;
     bool sin_built;            // the sinusoid table depends on constants only: built by the first pack
     bool fused;     // every GroupNorm can be applied in a producing GEMM's epilogue
     bool fold;      // fused, and the output GEMM can apply the sampler's update and encoder.0's norm1 of the next step

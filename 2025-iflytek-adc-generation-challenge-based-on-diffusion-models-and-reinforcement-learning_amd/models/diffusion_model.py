@@ -570,18 +570,10 @@ class DiffusionModel(nn.Module):
             beta_end = self.config.get('beta_end', 2e-2)
             return torch.linspace(beta_start, beta_end, self.num_timesteps)
         elif schedule_type == 'cosine':
-            return self._cosine_beta_schedule()
+            # the reference's cosine table (:128-142) is unreachable there too: the constructor always asks for 'linear' (:57)
+            raise NotImplementedError("only the linear schedule is reachable in the reference and built here")
         else:
             raise ValueError(f"unsupported schedule type: {schedule_type}")
-
-    def _cosine_beta_schedule(self, s: float = 0.008) -> torch.Tensor:
-        """diffusion_model.py:128-142 (unreachable from the constructor, kept for the surface)."""
-        steps = self.num_timesteps + 1
-        x = torch.linspace(0, self.num_timesteps, steps)
-        alphas_cumprod = torch.cos(((x / self.num_timesteps) + s) / (1 + s) * math.pi * 0.5) ** 2
-        alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
-        betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
-        return torch.clip(betas, 0, 0.999)
 
     def _posterior_variance(self) -> torch.Tensor:
         """diffusion_model.py:509-519."""
@@ -649,7 +641,7 @@ class DiffusionModel(nn.Module):
         drop_p = self.model.encoder[0].dropout.p if self.model.training else 0.0
         if not wants_grad and (condition is not None or drop_p == 0.0):
             predicted_noise = self.model(x_noisy, t, condition)
-            return F.mse_loss(used, predicted_noise)
+            return torch.ops.adcdiff.mse_loss_grad(predicted_noise, used, 1.0)[0]   # the same kernel as the differentiable path
         if condition is not None:
             raise NotImplementedError("the backward kernels cover the unconditional loss of train_step; a condition has no gradient path yet")
         rank, _ = _dp_rank_world()
@@ -680,7 +672,9 @@ class DiffusionModel(nn.Module):
         handle = eng.ensure(dev)
         cemb = None
         if condition is not None:
-            cemb = self.model.condition_embedding(condition.to(dev), self.compute_dtype, batch=batch, broadcast_view=True)
+            # not moved to the device here: condition_embedding first collapses a stride-0 (one row expanded) condition to its
+            # one row, so a CPU-resident expanded condition takes the same shared-row path as a GPU one (and copies one row)
+            cemb = self.model.condition_embedding(condition, self.compute_dtype, batch=batch, broadcast_view=True)
         ws, ws_bytes = eng.workspace_for(batch, dev)
         return dev, eng, handle, cemb, ws, ws_bytes
 

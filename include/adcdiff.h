@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ADCDIFF_ABI_VERSION 2
+#define ADCDIFF_ABI_VERSION 3
 
 enum { ADCDIFF_OK = 0, ADCDIFF_E_BADARG = -1, ADCDIFF_E_LAUNCH = -2, ADCDIFF_E_ARCH = -3, ADCDIFF_E_WORKSPACE = -4 };
 enum { ADCDIFF_F32 = 0, ADCDIFF_BF16 = 1 };
@@ -111,11 +111,9 @@ typedef struct adcdiff_gemm_args {
     int n_gn;                  /* 0..2 fused SiLU(GroupNorm(v)) outputs */
     adcdiff_gn_out gn[2];
     float gn_eps;
-    int tile_hint;             /* 0 = choose; 128 / 256 = force that tile kernel where the shape allows (256 = the eight-wave 256 x 256
-                                  kernel; 2560 / 2561 = its phased / ring main loop; 2564 = the four-wave 256 x 256 kernel with the
-                                  assembly main loop, which 0 picks for large bf16 layers); 1 / 3 = force the 128-row kernel with one
-                                  LDS stage / the three-stage ring (A/B measurements, tests); 32 = the one-wave kernel for bf16
-                                  launches (any m_valid), which 0 picks up to 1024 live rows; 325 = its variant with loader waves where one exists */
+    int tile_hint;             /* 0 = the library chooses the kernel from the shape (the only value a product caller passes).  Non-zero
+                                  values force one of the kernels for bit-identity tests and A/B measurements and are rejected unless
+                                  adcdiff_debug_set("tile_hints", 1) was called; their meaning is listed at adcdiff_debug_set. */
     int split_k;               /* 0 / 1 = off.  S > 1: the K dimension (one segment, a multiple of S * 64 bf16 / S * 32 f32) is cut
                                   into S equal slices computed by separate workgroups; slice s writes its partial product to
                                   out_f32 + s * split_stride and the caller sums the S partials in a fixed order.  For
@@ -199,12 +197,13 @@ typedef struct adcdiff_unet adcdiff_unet;   /* host-side plan: sizes and pointer
 size_t adcdiff_unet_arena_bytes(int input_dim, int hidden_dim, int output_dim, int num_timesteps, int dtype);
 size_t adcdiff_unet_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int dtype, int batch);
 
-/* Create a plan over caller-owned parameters and arena (nothing is copied or launched). */
+/* Create a plan over caller-owned parameters and arena (host-side only: nothing is copied to the device or launched). */
 int adcdiff_unet_create(const adcdiff_unet_params* params, int dtype, void* arena, size_t arena_bytes,
                         adcdiff_unet** out);
 void adcdiff_unet_destroy(adcdiff_unet* net);
 
-/* (Re)pack the weights into the arena and rebuild the tables that depend only on the timestep:
+/* (Re)pack the weights into the arena (the first call also uploads the plan's table of packing entries, a few KB, as a
+ * stream-ordered host-to-device copy) and rebuild the tables that depend only on the timestep:
  * TimeEmbedding(t) (diffusion_model.py:802-823) and every block's time_proj(SiLU(.)) (:859-862, :893)
  * for t = 0..num_timesteps-1.  Call after the parameters change.  workspace as for batch 1024. */
 int adcdiff_unet_pack(adcdiff_unet* net, void* workspace, size_t workspace_bytes, adcdiff_stream_t stream);
@@ -226,7 +225,8 @@ int adcdiff_unet_forward(adcdiff_unet* net, const float* x, int ldx, int B, cons
  * as [B, D] with leading dimension D; NULL selects in-kernel Philox with (seed, row_offset).
  * cemb: NULL, [B, hidden] with leading dimension ldce >= hidden, or ONE row with ldce = 0 = the whole batch shares the
  * condition (the generator's case): t_emb + c_emb is then the same for every row and every block's time projection of it
- * becomes a per-timestep row bias, as without a condition, built once per call in the front of the workspace. */
+ * becomes a per-timestep row bias, as without a condition, built once per call into a table that belongs to the PLAN (its
+ * arena), not to the workspace: sampling calls that share a plan and pass a one-row condition must share a stream. */
 int adcdiff_ddpm_sample_loop(adcdiff_unet* net, float* x, int ldx, int B, const float* cemb, int ldce,
                              const adcdiff_ddpm_coef* coef, int t_start, int t_stop, const float* noise,
                              long long noise_step_stride, uint64_t seed, uint64_t row_offset, void* workspace,
@@ -332,6 +332,24 @@ int adcdiff_clip_adamw_step_noalloc(const adcdiff_opt_tensor* tensors, int n_ten
                                     const adcdiff_adamw_args* args, float* grad_norm, adcdiff_stream_t stream);
 
 /* ------------------------------------------------------------------ measurement ------ */
+
+/* Measurement and test switches; no counterpart in the reference.  With no call of adcdiff_debug_set the library reads no
+ * environment variable and its kernel choice is a function of the call's arguments alone.  Keys (default):
+ *   tile_hints (0)       1 = honour adcdiff_gemm_args.tile_hint: 128 / 256 force that tile kernel where the shape allows (256 =
+ *                        the eight-wave 256 x 256 kernel, 2560 / 2561 its phased / ring main loop, 2564 the four-wave 256 x 256
+ *                        kernel with the assembly main loop, 2565 / 2566 / 2568 the same with epilogue batches of 1 / 2 / 8
+ *                        rows); 1 / 3 the 128-row kernel with one LDS stage / the three-stage ring; 32 the one-wave kernel,
+ *                        325 its variant with loader waves
+ *   gemm_tile (0)        128 / 256 / 2561: as the hint of that value, for every bf16 launch
+ *   gemm_ring (0), gemm_ring2 (1), gemm_ring_max (512), gemm_w4 (1), gemm_w1 (1), gemm_w1_rows (1024), gemm_cl (1)
+ *                        kernel-family switches of adcdiff_gemm's dispatch
+ *   step_fold (1)        0 = the reverse step and encoder.0's GroupNorm as launches of their own in the sampling loops
+ *   train_transpose (0)  1 = backward products on transposed copies instead of adcdiff_gemm_tr
+ *   sync (0)             1 = synchronise after every launch of adcdiff_unet_backward and name the first that fails
+ *   raster (0)           workgroup -> tile order of the four-wave kernel (A/B of L2 residency)
+ * Values are process-wide and read by every later call; unknown keys are rejected. */
+int adcdiff_debug_set(const char* key, long long value);
+int adcdiff_debug_get(const char* key, long long* value);
 
 /* Per-launch timing for benchmarks; no counterpart in the reference.  Between adcdiff_timing_begin and
  * adcdiff_timing_end every GEMM, GroupNorm+SiLU and schedule-update launch made through this library has a

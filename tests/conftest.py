@@ -44,24 +44,32 @@ def row_scaled_err(a, b):
 
 
 # Gates on the final latents of a reverse loop, about 3x what was observed on an MI355X for {tiny, Config A, Config B} x
-# {DDPM 1000, DDIM 50} (profiles/parity_r02.json, written by tools/parity_report.py; observed maxima in brackets):
-#   elem_max / elem_p999: |d_ij| / max(1, |ref_ij|)       fp32 [1.9e-4 / 1.2e-4]   bf16 [1.63 / 0.88]
-#   row_scaled:           |d_ij| / max(1, rms of ref row)  fp32 [2.0e-5]            bf16 [1.1e-2]
-# The latents grow to |x| ~ 180 (median) .. 990 (max) with random weights, and the bf16-operand path carries an ABSOLUTE error
-# of up to 2.6 whatever the element's own magnitude, so its per-element relative error is of order one for the elements that
-# happen to lie near zero; the row-scaled measure says what that error is against the scale of the row it sits in.
+# {DDPM 1000, DDIM 50} (profiles/parity_r02.json / parity_r03.json, written by tools/parity_report.py; observed maxima in brackets).
+# float32 -- a PER-ELEMENT relative tolerance:
+#   elem_max / elem_p999: |d_ij| / max(1, |ref_ij|)       [1.9e-4 / 1.2e-4]
+#   row_scaled:           |d_ij| / max(1, rms of ref row)  [2.0e-5]
+# bf16 operands -- an ABSOLUTE bound and a row-scaled one.  The latents grow to |x| ~ 180 (median) .. 990 (max) with random
+# weights and the bf16 path carries an absolute error of up to 2.64 whatever the element's own magnitude, so a per-element
+# relative figure is of order one for the elements that happen to lie near zero and constrains nothing; what is gated is
+#   abs_max:              |d_ij|                           [2.64]
+#   row_scaled:           |d_ij| / max(1, rms of ref row)  [1.1e-2]
 LOOP_GATE = {
     "fp32": dict(elem_max=6e-4, elem_p999=4e-4, row_scaled=6e-5),
-    "bf16": dict(elem_max=5.0, elem_p999=2.7, row_scaled=3.3e-2),
+    "bf16": dict(abs_max=8.0, row_scaled=3.3e-2),
 }
 
 
 def check_loop(out, ref, dtype, what=""):
     mx, p999 = elem_err(out, ref)
     rs = row_scaled_err(out, ref)
+    amax = float(np.abs(np.asarray(out, dtype=np.float64) - np.asarray(ref, dtype=np.float64)).max())
     gate = LOOP_GATE[dtype]
-    print("parity %s %s: per-element max %.3e  99.9%% %.3e  row-scaled %.3e" % (what, dtype, mx, p999, rs))
-    assert mx <= gate["elem_max"] and p999 <= gate["elem_p999"] and rs <= gate["row_scaled"], (what, dtype, mx, p999, rs)
+    print("parity %s %s: per-element max %.3e  99.9%% %.3e  row-scaled %.3e  absolute max %.3e" % (what, dtype, mx, p999, rs, amax))
+    assert np.isfinite(amax), (what, dtype)
+    if dtype == "fp32":
+        assert mx <= gate["elem_max"] and p999 <= gate["elem_p999"] and rs <= gate["row_scaled"], (what, dtype, mx, p999, rs)
+    else:
+        assert amax <= gate["abs_max"] and rs <= gate["row_scaled"], (what, dtype, amax, rs)
 
 
 @pytest.fixture(scope="session")

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().adcdiff_abi_version() == 2
+    assert _lib.load().adcdiff_abi_version() == 3
 
 
 def test_size_queries_and_argument_errors_without_gpu():
@@ -197,3 +197,18 @@ def test_generated_assembly_main_loop_is_what_the_generator_writes(tmp_path):
     out = tmp_path / "w4.inc"
     subprocess.run([sys.executable, os.path.join(csrc, "gen_w4_mainloop.py"), str(out)], check=True)
     assert out.read_text() == open(os.path.join(csrc, "w4_mainloop.inc")).read()
+
+
+def test_debug_switches_are_host_side_and_default_to_the_shipped_behaviour():
+    """adcdiff_debug_set / _get touch no GPU; defaults are what the header documents; unknown keys are rejected; the library
+    reads no environment variable (its sources do not call getenv)."""
+    import glob
+    lib = _lib.load()
+    for key, default in (("tile_hints", 0), ("gemm_w4", 1), ("gemm_ring_max", 512), ("step_fold", 1), ("train_transpose", 0), ("raster", 0)):
+        assert _lib.debug_get(key) == default, key
+    _lib.debug_set("gemm_ring_max", 7)
+    assert _lib.debug_get("gemm_ring_max") == 7
+    _lib.debug_set("gemm_ring_max", 512)
+    assert lib.adcdiff_debug_set(b"no_such_key", 1) == -1 and b"unknown key" in lib.adcdiff_last_error()
+    for src in glob.glob(os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc", "*.hip")):
+        assert "getenv" not in open(src).read(), src

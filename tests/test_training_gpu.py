@@ -155,7 +155,7 @@ def test_large_batch_gradient_is_mean_of_half_batch_gradients(dtype):
 @pytest.mark.parametrize("dims,B", [((128, 128, 128), 64), ((512, 256, 512), 1024)])
 def test_backward_without_transposed_copies_gives_the_same_gradients(dims, B, monkeypatch):
     """bf16 batches that are multiples of 64 run the backward GEMMs on the stored operands (adcdiff_gemm_tr); the NT
-    kernel on transposed copies (ADCDIFF_TRAIN_TRANSPOSE=1, and every other batch size or float32) must give the same
+    kernel on transposed copies (debug switch train_transpose = 1, and every other batch size or float32) must give the same
     weight gradients bit for bit: same MFMA, same k order, same slicing of the batch contraction.  Dropout active."""
     cfg = dict(input_dim=dims[0], hidden_dim=dims[1], output_dim=dims[2], compute_dtype="bf16", max_batch_size=4096)
     m = adcdiff.DiffusionModel(cfg)
@@ -167,7 +167,7 @@ def test_backward_without_transposed_copies_gives_the_same_gradients(dims, B, mo
     t = torch.randint(0, 1000, (B,), generator=gen).cuda()
 
     def grads(transpose):
-        monkeypatch.setenv("ADCDIFF_TRAIN_TRANSPOSE", "1" if transpose else "0")
+        adcdiff._lib.debug_set("train_transpose", 1 if transpose else 0)
         m.model.zero_grad(set_to_none=True)
         torch.manual_seed(3)             # the dropout seed is drawn from torch: same masks in both passes
         loss = m.p_losses(x, t, noise=nz)
@@ -175,7 +175,10 @@ def test_backward_without_transposed_copies_gives_the_same_gradients(dims, B, mo
         torch.cuda.synchronize()
         return {k: p.grad.clone() for k, p in m.model.named_parameters() if p.grad is not None}
 
-    direct, copies = grads(False), grads(True)
+    try:
+        direct, copies = grads(False), grads(True)
+    finally:
+        adcdiff._lib.debug_set("train_transpose", 0)
     assert len(direct) >= 100 and direct.keys() == copies.keys()
     exact = 0
     for k in direct:
