@@ -380,12 +380,13 @@ def test_public_p_losses_honours_the_autograd_contract():
     assert len(have) >= 100 and all(torch.isfinite(g).all() for g in have)
     m.p_losses(x[8:], t[8:], noise=nz[8:]).backward()
     for p, g in zip(params, got):
-        if g is not None:
-            assert torch.equal(p.grad, g)
+        if g is not None:   # bias and GroupNorm gradients are summed with atomics: equal up to the summation order
+            assert torch.allclose(p.grad, g, rtol=1e-4, atol=1e-6 * float(g.abs().max()))
     # a scaled loss scales the gradients (the factor is applied to d(eps) before the backward kernels)
     m.model.zero_grad(set_to_none=True)
     (m.p_losses(x[8:], t[8:], noise=nz[8:]) * 0.25).backward()
-    assert torch.allclose(w.grad, 0.25 * got[params.index(w)], rtol=1e-5, atol=1e-9)
+    g_w = next(g for p, g in zip(params, got) if p is w)
+    assert torch.allclose(w.grad, 0.25 * g_w, rtol=1e-5, atol=1e-9)
 
 
 def test_validation_loss_follows_training_mode():
