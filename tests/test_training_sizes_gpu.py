@@ -1,0 +1,124 @@
+"""Training at the BASELINE sizes against the reference's own numbers (tests/golden/train_a.npz, train_b.npz, tiny_cond.npz,
+written by tests/golden/make_golden_train.py from the unmodified reference): loss, gradients and one AdamW step at emb 512 /
+hidden 256 and hidden 128, batch 32, float32 and bf16 operands.
+
+Gates are about 3x what an MI355X measured (profiles/r03_train_parity.json; measured values in the table below).
+  grad_rel = max |got - ref| / max |ref| per gradient tensor (worst tensor);  grad_l2 = ||got - ref|| / ||ref|| (worst tensor)
+                      loss        grad_rel    grad_l2     global norm   weights after the step (lr = 1e-4)
+  fp32  tiny / A / B  0 / 1e-7 / 0   1.3e-5 / 6.3e-6 / 8.3e-5   1.0e-5 / 5.9e-6 / 3.3e-5   1e-6 / 1e-8 / 5e-6   all within 6e-6
+  bf16  tiny / A / B  4e-4 / 5e-6 / 4e-5   4.5e-2 / 2.8e-2 / 0.25   4.0e-2 / 1.8e-2 / 0.11   1e-6 / 4e-4 / 1.5e-2   97-99 % within 4e-6, max 2.0e-4
+bf16 operands at hidden 128 have GroupNorm groups of four channels, whose 1 / std amplifies operand rounding: the 0.25 is one
+narrow layer (decoder.3.linear2, 128 x 128).  AdamW's first step moves every entry by lr * sign(g) (|m| / sqrt(v) = 1), so an
+entry whose gradient changes sign under bf16 rounding lands 2 lr = 2e-4 away; the gate is on the fraction of such entries."""
+import numpy as np
+import pytest
+import torch
+
+import adcdiff
+from conftest import load_golden
+from oracle import philox
+from oracle.weights import make_weights
+
+pytestmark = pytest.mark.gpu
+SEED = 2025
+CASES = {"tiny_cond": (128, 128, 128), "train_a": (512, 256, 512), "train_b": (512, 128, 512)}
+GATES = {
+    # (fixture, dtype): loss, grad_rel, grad_l2, global norm, fraction of post-step entries within 4e-6 (fp32: 6e-6), their max
+    ("tiny_cond", "fp32"): (1e-6, 4e-5, 3e-5, 4e-6, 0.999, 2e-5),
+    ("train_a", "fp32"): (1e-6, 2e-5, 2e-5, 1e-6, 0.999, 2e-5),
+    ("train_b", "fp32"): (1e-6, 2.5e-4, 1e-4, 1.5e-5, 0.999, 2e-5),
+    ("tiny_cond", "bf16"): (1.5e-3, 0.14, 0.12, 1e-4, 0.95, 2.05e-4),
+    ("train_a", "bf16"): (2e-4, 9e-2, 5.5e-2, 1.5e-3, 0.95, 2.05e-4),
+    ("train_b", "bf16"): (2e-4, 0.75, 0.33, 4.5e-2, 0.93, 2.05e-4),
+}
+
+
+def cu(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda").to(dtype)
+
+
+def stored_names(g, prefix):
+    out = set()
+    for k in g.files:
+        if k.startswith(prefix):
+            k = k[len(prefix):]
+            for suf in (".sample", ".stride", ".norm"):
+                if k.endswith(suf):
+                    k = k[:-len(suf)]
+            out.add(k)
+    return sorted(out)
+
+
+def against(g, key, got):
+    got = got.detach().float().cpu().numpy()
+    if key in g.files:
+        return got.ravel().astype(np.float64), g[key].ravel().astype(np.float64)
+    return got.ravel()[::int(g[key + ".stride"])].astype(np.float64), g[key + ".sample"].astype(np.float64)
+
+
+def build(dims, dtype):
+    m = adcdiff.DiffusionModel(dict(input_dim=dims[0], hidden_dim=dims[1], output_dim=dims[2], compute_dtype=dtype, max_batch_size=4096,
+                                    use_mixed_precision=(dtype == "bf16")))
+    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(1234, *dims).items()})
+    return m
+
+
+def grad_errors(g, prefix, grads):
+    rel, l2 = {}, {}
+    for name in stored_names(g, prefix):
+        got, ref = against(g, prefix + name, grads[name])
+        rel[name] = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12))
+        l2[name] = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+    return rel, l2
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_loss_and_gradients_match_the_reference_at_baseline_sizes(name, dtype):
+    g, dims = load_golden(name), CASES[name]
+    gate = GATES[(name, dtype)]
+    B, D = g["x0"].shape
+    m = build(dims, dtype)
+    m.model.eval()                                   # the capture was taken without dropout
+    nz = cu(philox.normal(SEED, philox.STREAM_QNOISE, 0, 0, B, D))
+    loss = m.p_losses(cu(g["x0"]), cu(g["t"], torch.int64), noise=nz)
+    assert abs(float(loss.detach()) - float(g["p_losses"])) <= gate[0] * float(g["p_losses"])
+    loss.backward()
+    grads = {k: p.grad for k, p in m.model.named_parameters() if p.grad is not None}
+    rel, l2 = grad_errors(g, "grad.", grads)
+    assert len(rel) >= 16
+    print("training parity %s %s: worst grad_rel %.2e (%s), worst grad_l2 %.2e (%s)" % (name, dtype, max(rel.values()), max(rel, key=rel.get),
+                                                                                      max(l2.values()), max(l2, key=l2.get)))
+    assert max(rel.values()) <= gate[1], rel
+    assert max(l2.values()) <= gate[2], l2
+    sq = sum(float((p.double() ** 2).sum()) for p in grads.values())
+    assert abs(np.sqrt(sq) - float(g["grad_global_norm"])) <= gate[3] * float(g["grad_global_norm"])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_train_step_matches_the_reference_at_baseline_sizes(name, dtype, monkeypatch):
+    g, dims = load_golden(name), CASES[name]
+    gate = GATES[(name, dtype)]
+    B, D = g["x0"].shape
+    m = build(dims, dtype)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0                              # as in the capture: train_step calls .train()
+    nz = cu(philox.normal(SEED, philox.STREAM_QNOISE, 0, 0, B, D))
+    real_randint, real_q = torch.randint, adcdiff.ops.q_sample
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: cu(g["t"], torch.int64) if "device" in k else real_randint(*a, **k))
+    monkeypatch.setattr(adcdiff.ops, "q_sample", lambda *a, **k: real_q(*a, **{**k, "noise": nz}))
+    res = m.train_step(cu(g["x0"]), 0)
+    assert abs(res["loss"] - float(g["train_step_loss"])) <= gate[0] * float(g["train_step_loss"])
+    sd = m.model.state_dict()
+    w0 = make_weights(1234, *dims)
+    names = stored_names(g, "train_step_after.")
+    assert len(names) >= 6
+    for k in names:
+        got, ref = against(g, "train_step_after." + k, sd[k])
+        d = np.abs(got - ref)
+        near = 6e-6 if dtype == "fp32" else 4e-6
+        assert (d < near).mean() >= gate[4] and d.max() <= gate[5], (k, float(d.max()), float((d < near).mean()))
+        before = w0[k].ravel() if ("train_step_after." + k) in g.files else w0[k].ravel()[::int(g["train_step_after." + k + ".stride"])]
+        assert np.abs(got - before).max() > 5e-5, k   # the step really moved the weights (lr = 1e-4)
