@@ -63,7 +63,8 @@ class BlockGrads(C.Structure):
 class UnetGrads(C.Structure):
     _fields_ = [("time_lin1_w", c_fp), ("time_lin1_b", c_fp), ("time_lin2_w", c_fp), ("time_lin2_b", c_fp),
                 ("blocks", BlockGrads * 10),
-                ("out_norm_w", c_fp), ("out_norm_b", c_fp), ("out_w", c_fp), ("out_b", c_fp)]
+                ("out_norm_w", c_fp), ("out_norm_b", c_fp), ("out_w", c_fp), ("out_b", c_fp),
+                ("cond0_w", c_fp), ("cond0_b", c_fp), ("cond2_w", c_fp), ("cond2_b", c_fp)]
 
 
 class TimingRecord(C.Structure):
@@ -115,7 +116,8 @@ SIGNATURES = {
                                            C.POINTER(DdimCoef), C.c_int, c_fp, C.c_longlong, C.c_uint64, C.c_uint64, c_fp,
                                            C.c_size_t, c_fp]),
     "adcdiff_unet_train_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "adcdiff_unet_train_forward": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp, C.c_float, C.c_uint64, c_fp, C.c_int, c_fp, C.c_size_t, c_fp]),
+    "adcdiff_unet_train_forward": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp, C.c_int, C.c_float, C.c_uint64, c_fp, C.c_int, c_fp, C.c_size_t,
+                                             c_fp]),
     "adcdiff_mse_loss_grad": (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_float, c_fp, c_fp]),
     "adcdiff_unet_backward": (C.c_int, [c_fp, c_fp, C.c_int, C.POINTER(UnetGrads), c_fp, C.c_size_t, c_fp]),
     "adcdiff_latent_summary": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp]),

@@ -219,6 +219,30 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__
     if (threadIdx.x == 0) atomicAdd(loss, scale * ((part[0] + part[1]) + (part[2] + part[3])) / (float)n);
 }
 
+// dst[r, c] += src[r, c] for r < rows (leading dimensions lds_ / ldd)
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, int rows, int cols) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rows * cols) return;
+    const long r = e / cols;
+    const int c = (int)(e - r * cols);
+    dst[r * ldd + c] += src[r * lds_ + c];
+}
+
+// dz[r, j] = ds[r, j] * silu'(te_table[t_r, j] + cemb[r, j]): backward of s = SiLU(t_emb + c_emb) (diffusion_model.py:766, 859-862)
+__global__ __launch_bounds__(256) void cond_silu_bwd_kernel(const float* __restrict__ te_table, int ldt, int table_rows, const int64_t* __restrict__ t_rows,
+                                                            const float* __restrict__ cemb, int ldce, const float* __restrict__ ds,
+                                                            float* __restrict__ dz, int rows, int H) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rows * H) return;
+    const long r = e / H;
+    const int j = (int)(e - r * H);
+    long t = (long)t_rows[r];
+    t = t < 0 ? 0 : t >= table_rows ? table_rows - 1 : t;   // as the forward pass clamps it
+    const float v = te_table[t * ldt + j] + cemb[r * ldce + j];
+    const float sig = 1.0f / (1.0f + expf(-v));
+    dz[e] = ds[e] * (sig * (1.0f + v * (1.0f - sig)));
+}
+
 __global__ __launch_bounds__(256) void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, long n, int accumulate) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e < n) dst[e] = (accumulate ? dst[e] : 0.0f) + src[e];
@@ -370,12 +394,50 @@ static int copy_f32(const float* src, float* dst, long n, int accumulate, hipStr
     return check_launch("copy_f32");
 }
 
+static int add_rows(const float* src, long lds_, float* dst, long ldd, int rows, int cols, hipStream_t st) {
+    TimingScope ts(ADCDIFF_KIND_OTHER, rows, cols, 0, 0.0, (double)rows * cols * 12.0, st);
+    const long total = (long)rows * cols;
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, lds_, dst, ldd, rows, cols);
+    return check_launch("add_rows");
+}
+
+static int silu_bwd(const float* x, const float* dy, float* dx, long nel, hipStream_t st) {
+    TimingScope ts(ADCDIFF_KIND_OTHER, 1, 0, 0, 0.0, (double)nel * 12.0, st);
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, x, dy, dx, nel);
+    return check_launch("silu_bwd");
+}
+
+// condition_embed (diffusion_model.py:694-698) inside a training forward, with what its backward needs left in the workspace:
+// the condition in the operand type, the hidden pre-activation (float32), the hidden activation (operand type), the output.
+static int cond_embed_taped(adcdiff_unet* n, const float* cond, int ldc, int B, Bump& ws, bool dry, hipStream_t st, Tape* tape) {
+    const int Bp = (int)round_up((size_t)B, 128), H = n->H, D = n->D, dt = n->dtype;
+    const size_t e = (size_t)n->esz;
+    void* c_op = ws.take((size_t)Bp * D * e);
+    float* pre = (float*)ws.take((size_t)Bp * H * 4);
+    void* hid = ws.take((size_t)Bp * H * e);
+    float* cemb = (float*)ws.take((size_t)Bp * H * 4);
+    if (dry) return ADCDIFF_OK;
+    TRY(cast_pack(cond, ldc, dt, c_op, D, 0, B, D, st));
+    adcdiff_gemm_args g = gemm_args(dt, Bp, B, H);
+    g.nseg = 1; g.A[0] = c_op; g.lda[0] = D; g.K[0] = D; g.W = n->w_c0; g.ldw = D; g.bias = n->prm.cond0_b;
+    g.out_f32 = pre; g.ldo_f32 = H;
+    TRY(gemm_dispatch(g, st));
+    TRY(temb_silu(pre, H, B, nullptr, -1, nullptr, 0, dt, hid, H, B, H, st));   // hid = SiLU(pre), row r of the "table" is row r
+    g = gemm_args(dt, Bp, B, H);
+    g.nseg = 1; g.A[0] = hid; g.lda[0] = H; g.K[0] = H; g.W = n->w_c2; g.ldw = H; g.bias = n->prm.cond2_b;
+    g.out_f32 = cemb; g.ldo_f32 = H;
+    TRY(gemm_dispatch(g, st));
+    tape->cond = true; tape->c_op = c_op; tape->c_pre = pre; tape->c_hid = hid; tape->cemb = cemb;
+    return ADCDIFF_OK;
+}
+
 }  // namespace adcdiff
 
 using namespace adcdiff;
 
 static size_t train_forward_bytes(adcdiff_unet* n, int B) {
     Bump ws(nullptr, 0);
+    cond_embed_taped(n, nullptr, 0, B, ws, true, nullptr, nullptr);   // sized for the conditional case, the larger one
     forward_unfused(n, nullptr, 0, B, nullptr, 0, nullptr, 0, nullptr, 0, ws, true, nullptr);
     return ws.off;
 }
@@ -396,8 +458,8 @@ extern "C" size_t adcdiff_unet_train_workspace_bytes(int input_dim, int hidden_d
     return train_forward_bytes(&n, batch) + train_backward_bytes(&n, batch);
 }
 
-extern "C" int adcdiff_unet_train_forward(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, float dropout_p,
-                                          uint64_t dropout_seed, float* eps, int lde, void* workspace, size_t workspace_bytes,
+extern "C" int adcdiff_unet_train_forward(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, const float* cond, int ldc,
+                                          float dropout_p, uint64_t dropout_seed, float* eps, int lde, void* workspace, size_t workspace_bytes,
                                           adcdiff_stream_t stream_) {
     if (!n || !n->packed) return fail(ADCDIFF_E_BADARG, "unet_train_forward: plan missing or not packed");
     if (!x || !eps || !t_rows || B <= 0 || ldx < n->D || lde < n->O || !aligned16(x) || !aligned16(eps) || ldx % 4 || lde % 4)
@@ -408,9 +470,12 @@ extern "C" int adcdiff_unet_train_forward(adcdiff_unet* n, const float* x, int l
     if (workspace_bytes < need) return fail(ADCDIFF_E_WORKSPACE, "unet_train_forward: workspace of %zu bytes, %zu needed", workspace_bytes, need);
     for (int i = 0; i < 10; ++i)
         if (n->blk[i].cout % 128 != 0) return fail(ADCDIFF_E_BADARG, "training needs layer widths that are multiples of 128 (got %d)", n->blk[i].cout);
+    if (cond && (ldc < n->D || !aligned16(cond) || ldc % 4)) return fail(ADCDIFF_E_BADARG, "unet_train_forward: condition misaligned or ldc=%d < %d", ldc, n->D);
     Bump ws(workspace, workspace_bytes);
     n->tape = Tape{};
-    return forward_unfused(n, x, ldx, B, t_rows, 0, nullptr, 0, eps, lde, ws, false, as_stream(stream_), &n->tape, dropout_p, dropout_seed);
+    if (cond) TRY(cond_embed_taped(n, cond, ldc, B, ws, false, as_stream(stream_), &n->tape));
+    else cond_embed_taped(n, nullptr, 0, B, ws, true, nullptr, nullptr);   // the same carving with and without a condition
+    return forward_unfused(n, x, ldx, B, t_rows, 0, n->tape.cemb, n->H, eps, lde, ws, false, as_stream(stream_), &n->tape, dropout_p, dropout_seed);
 }
 
 extern "C" int adcdiff_mse_loss_grad(const float* pred, int ldp, const float* target, int ldt, float* dpred, int ldd, int B, int D,
@@ -461,12 +526,24 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
     bool dO_written[10];
     for (int i = 0; i < 10; ++i) { dO[i] = (float*)ws.take((size_t)Bp * n->blk[i].cout * 4); dO_written[i] = false; }
     float* d_tb = (float*)ws.take((size_t)Tp * SN * 4);
-    if (!dry && hipMemsetAsync(d_tb, 0, (size_t)Tp * SN * 4, st) != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "unet_backward: memset failed");
+    // conditional forward (per-row condition): the time term of a row is time_proj(s_r), s_r = SiLU(t_emb[t_r] + c_emb_r), an
+    // operand of every block's first GEMM; its gradient d(s) [Bp, H] is summed over the blocks, nothing goes through the
+    // per-timestep table of projections
+    const bool cond = tp.cond;
+    float* d_s_rows = (float*)ws.take((size_t)Bp * H * 4);
+    void* sT = ws.take((size_t)H * Bp * e);      // s transposed, for the path on transposed copies
+    if (!dry) {
+        if (hipMemsetAsync(cond ? d_s_rows : d_tb, 0, cond ? (size_t)Bp * H * 4 : (size_t)Tp * SN * 4, st) != hipSuccess)
+            return fail(ADCDIFF_E_LAUNCH, "unet_backward: memset failed");
+        if (cond && (!gr->cond0_w || !gr->cond0_b || !gr->cond2_w || !gr->cond2_b))
+            return fail(ADCDIFF_E_BADARG, "unet_backward: the forward was conditional, condition_embed gradient destinations are needed");
+    }
 
     // ---- output head: eps = out_layer(a_out), a_out = SiLU(output_norm(o9)) (diffusion_model.py:786-788)
     // bf16 with whole 64-row contraction tiles: the backward GEMMs read d(y), the saved activations and the packed weights as
     // they are (gemm_tr); otherwise the NT kernel on transposed copies
     const bool direct = dt == ADCDIFF_BF16 && B % 64 == 0 && direct_enabled();
+    if (cond && !direct) RUN(transpose_op(tp.s_op, H, B, Bp, H, dt, sT, st));
     if (direct) {
         void* dE_rm = ws.take((size_t)Bp * O * e);
         RUN(cast_rows(d_eps, lde, B, Bp, O, dE_rm, O, gr->out_b, nullptr, st));
@@ -502,7 +579,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         const int cin = b.cin, cout = b.cout;
         float* d_raw = nullptr;
         float* d_a1 = nullptr;
-        long ld_raw = cin;
+        long ld_raw = cin, ld_a1 = cin;
         if (direct) {
             // (1) dO in bf16; its column sums are d(linear2.bias) (= d(residual_proj.bias))
             void* dY = ws.take((size_t)Bp * cout * e);
@@ -527,7 +604,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
                             cout, 0, g.norm2_w, g.norm2_b, ws, dry, st));
             // (6) d(h1) in bf16: column sums are d(linear1.bias) = d(time_proj.bias); (7) rows go to the timestep table
             RUN(cast_rows(d_h1, cout, B, Bp, cout, dY, cout, g.linear1_b, g.time_proj_b, st));
-            {
+            if (!cond) {
                 const long total = (long)B * cout;
                 if (!dry) {
                     TimingScope ts(ADCDIFF_KIND_OTHER, B, cout, 0, 0.0, (double)total * 12.0, st);
@@ -538,8 +615,12 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             }
             // (8) d(linear1.weight) = d_h1^T a1; (9) d(a1) = d_h1 W1 (the first cin columns of the packed [W1 | Wtp])
             TRY(gemm_dw_direct(dY, cout, bt.a1, cin, cout, cin, B, g.linear1_w, cin, cin, ws, dry, st));
-            d_a1 = (float*)ws.take((size_t)Bp * cin * 4);
-            RUN(gemm_tr(false, dY, cout, b.w1cat, b.ldw1, d_a1, cin, Bp, cin, cout, 1, 0, st));
+            // with a condition also d(time_proj.weight) = d_h1^T s, and [d(a1) | d(s)] = d_h1 [W1 | Wtp] in one product
+            if (cond || dry) TRY(gemm_dw_direct(dY, cout, tp.s_op, H, cout, H, B, g.time_proj_w, H, H, ws, dry, st));
+            ld_a1 = cond ? cin + H : cin;
+            d_a1 = (float*)ws.take((size_t)Bp * (cin + H) * 4);
+            RUN(gemm_tr(false, dY, cout, b.w1cat, b.ldw1, d_a1, ld_a1, Bp, (int)ld_a1, cout, 1, 0, st));
+            if (cond) RUN(add_rows(d_a1 + cin, ld_a1, d_s_rows, H, B, H, st));
         } else {
             // (1) dO in the operand type, row-major and transposed; its column sums are d(linear2.bias) (= d(residual_proj.bias))
             void* dO_rm = ws.take((size_t)Bp * cout * e);
@@ -573,13 +654,23 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             // (6) d(h1): column sums are d(linear1.bias) = d(time_proj.bias); (7) rows go to the timestep table
             RUN(cast_transpose<float>(d_h1, cout, B, Bp, cout, dt, dO_rm, cout, dO_t, Bp, g.linear1_b, st));
             RUN(copy_f32(g.linear1_b, g.time_proj_b, cout, 0, st));
-            {
+            if (!cond) {
                 const long total = (long)B * cout;
                 if (!dry) {
                     TimingScope ts(ADCDIFF_KIND_OTHER, B, cout, 0, 0.0, (double)total * 12.0, st);
                     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_h1, (long)cout, tp.t_rows, B,
                                        cout, d_tb, (long)SN, b.tb_off, n->T);
                     TRY(check_launch("scatter_add_rows"));
+                }
+            }
+            if (cond || dry) {
+                // with a condition: d(time_proj.weight) = d_h1^T s and d(s) += d_h1 Wtp
+                TRY(gemm_dw(dt, dO_t, sT, cout, H, Bp, g.time_proj_w, ws, dry, st));
+                float* d_si = (float*)ws.take((size_t)Bp * H * 4);
+                if (cond) {
+                    RUN(cast_transpose<float>(q.time_proj_w, H, cout, cout, H, dt, nullptr, 0, wT, cout, nullptr, st));
+                    RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, H, cout, d_si, H, st));
+                    RUN(add_rows(d_si, H, d_s_rows, H, B, H, st));
                 }
             }
             // (8) d(linear1.weight) = d_h1^T a1; (9) d(a1) = d_h1 W1
@@ -600,7 +691,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             const int acc = src >= 0 && dO_written[src] ? 1 : 0;
             const float* add = b.has_res ? d_raw + col : dO[i];     // Identity residual passes dO straight through
             const long ldadd = b.has_res ? ld_raw : cout;
-            TRY(gn_silu_bwd(bt.in_f32[k], bt.in_ld[k], d_a1 + col, cin, B, b.part_c[k], b.part_c[k] / b.gs1, q.norm1_w + col, q.norm1_b + col, 0.0f,
+            TRY(gn_silu_bwd(bt.in_f32[k], bt.in_ld[k], d_a1 + col, ld_a1, B, b.part_c[k], b.part_c[k] / b.gs1, q.norm1_w + col, q.norm1_b + col, 0.0f,
                             0, 0, 0, add, ldadd, dst, lddst, acc, g.norm1_w + col, g.norm1_b + col, ws, dry, st));
             if (src >= 0) dO_written[src] = true;
             col += b.part_c[k];
@@ -610,49 +701,100 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
     //      te_pre = sinusoid W1^T + b1 (all float32, M = Tp rows of which only the drawn timesteps carry gradient)
     ws.off = mark;
     {
-        float* d_s = nullptr;
-        if (direct) {
-            // the two large products of the branch (contraction over the Tp timesteps and over all sumN time_proj outputs) on bf16
-            // copies of d_tb, s_table and the stacked time_proj weights, read as stored
-            void* dtb_op = ws.take((size_t)Tp * SN * e);
-            RUN(cast_transpose<float>(d_tb, SN, Tp, Tp, SN, dt, dtb_op, SN, nullptr, 0, nullptr, st));
-            void* s_op = ws.take((size_t)Tp * H * e);
-            RUN(cast_transpose<float>(n->s_table, H, Tp, Tp, H, dt, s_op, H, nullptr, 0, nullptr, st));
-            for (int i = 0; i < 10; ++i)
-                TRY(gemm_dw_direct((const char*)dtb_op + (size_t)n->blk[i].tb_off * e, SN, s_op, H, n->blk[i].cout, H, Tp, gr->blocks[i].time_proj_w, H,
-                                   H, ws, dry, st));
-            void* wtp_op = ws.take((size_t)SN * H * e);
-            RUN(cast_pack(n->wtp_all, H, dt, wtp_op, H, 0, SN, H, st));
-            d_s = (float*)ws.take((size_t)Tp * H * 4);
-            int slices = 1;
-            for (int c = 16; c > 1; --c)
-                if (SN % (64 * c) == 0) { slices = c; break; }
-            float* part = slices > 1 ? (float*)ws.take((size_t)slices * Tp * H * 4) : d_s;
-            RUN(gemm_tr(false, dtb_op, SN, wtp_op, H, part, H, Tp, H, SN, slices, (long)Tp * H, st));
-            if (slices > 1 && !dry) {
-                const long n4 = (long)Tp * H / 4;
-                TimingScope ts(ADCDIFF_KIND_OTHER, Tp, H, 0, 0.0, (double)Tp * H * 4.0 * (slices + 1), st);
-                hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, slices, (long)Tp * H, n4, d_s, H, (long)H);
-                TRY(check_launch("sum_partials"));
+        float* d_te = (float*)ws.take((size_t)Tp * H * 4);   // gradient of the TimeEmbedding table (rows = timesteps)
+        const size_t tail = ws.off;
+        if (!cond || dry) {
+            float* d_s = nullptr;
+            if (direct) {
+                // the two large products of the branch (contraction over the Tp timesteps and over all sumN time_proj outputs) on bf16
+                // copies of d_tb, s_table and the stacked time_proj weights, read as stored
+                void* dtb_op = ws.take((size_t)Tp * SN * e);
+                RUN(cast_transpose<float>(d_tb, SN, Tp, Tp, SN, dt, dtb_op, SN, nullptr, 0, nullptr, st));
+                void* s_op = ws.take((size_t)Tp * H * e);
+                RUN(cast_transpose<float>(n->s_table, H, Tp, Tp, H, dt, s_op, H, nullptr, 0, nullptr, st));
+                for (int i = 0; i < 10; ++i)
+                    TRY(gemm_dw_direct((const char*)dtb_op + (size_t)n->blk[i].tb_off * e, SN, s_op, H, n->blk[i].cout, H, Tp, gr->blocks[i].time_proj_w, H,
+                                       H, ws, dry, st));
+                void* wtp_op = ws.take((size_t)SN * H * e);
+                RUN(cast_pack(n->wtp_all, H, dt, wtp_op, H, 0, SN, H, st));
+                d_s = (float*)ws.take((size_t)Tp * H * 4);
+                int slices = 1;
+                for (int c = 16; c > 1; --c)
+                    if (SN % (64 * c) == 0) { slices = c; break; }
+                float* part = slices > 1 ? (float*)ws.take((size_t)slices * Tp * H * 4) : d_s;
+                RUN(gemm_tr(false, dtb_op, SN, wtp_op, H, part, H, Tp, H, SN, slices, (long)Tp * H, st));
+                if (slices > 1 && !dry) {
+                    const long n4 = (long)Tp * H / 4;
+                    TimingScope ts(ADCDIFF_KIND_OTHER, Tp, H, 0, 0.0, (double)Tp * H * 4.0 * (slices + 1), st);
+                    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, slices, (long)Tp * H, n4, d_s, H, (long)H);
+                    TRY(check_launch("sum_partials"));
+                }
+            } else {
+                float* dTB_t = (float*)ws.take((size_t)SN * Tp * 4);
+                RUN(cast_transpose<float>(d_tb, SN, Tp, Tp, SN, ADCDIFF_F32, nullptr, 0, dTB_t, Tp, nullptr, st));
+                float* s_tab_t = (float*)ws.take((size_t)H * Tp * 4);
+                RUN(cast_transpose<float>(n->s_table, H, Tp, Tp, H, ADCDIFF_F32, nullptr, 0, s_tab_t, Tp, nullptr, st));
+                for (int i = 0; i < 10; ++i)
+                    RUN(gemm_simple(ADCDIFF_F32, dTB_t + (size_t)n->blk[i].tb_off * Tp, Tp, s_tab_t, Tp, n->blk[i].cout, 0, H, Tp, gr->blocks[i].time_proj_w, H, st));
+                float* wtpT = (float*)ws.take((size_t)H * SN * 4);
+                RUN(cast_transpose<float>(n->wtp_all, H, SN, SN, H, ADCDIFF_F32, nullptr, 0, wtpT, SN, nullptr, st));
+                d_s = (float*)ws.take((size_t)Tp * H * 4);
+                RUN(gemm_simple(ADCDIFF_F32, d_tb, SN, wtpT, SN, Tp, 0, H, SN, d_s, H, st));
             }
-        } else {
-            float* dTB_t = (float*)ws.take((size_t)SN * Tp * 4);
-            RUN(cast_transpose<float>(d_tb, SN, Tp, Tp, SN, ADCDIFF_F32, nullptr, 0, dTB_t, Tp, nullptr, st));
-            float* sT = (float*)ws.take((size_t)H * Tp * 4);
-            RUN(cast_transpose<float>(n->s_table, H, Tp, Tp, H, ADCDIFF_F32, nullptr, 0, sT, Tp, nullptr, st));
-            for (int i = 0; i < 10; ++i)
-                RUN(gemm_simple(ADCDIFF_F32, dTB_t + (size_t)n->blk[i].tb_off * Tp, Tp, sT, Tp, n->blk[i].cout, 0, H, Tp, gr->blocks[i].time_proj_w, H, st));
-            float* wtpT = (float*)ws.take((size_t)H * SN * 4);
-            RUN(cast_transpose<float>(n->wtp_all, H, SN, SN, H, ADCDIFF_F32, nullptr, 0, wtpT, SN, nullptr, st));
-            d_s = (float*)ws.take((size_t)Tp * H * 4);
-            RUN(gemm_simple(ADCDIFF_F32, d_tb, SN, wtpT, SN, Tp, 0, H, SN, d_s, H, st));
+            if (!dry && !cond) {
+                TimingScope ts(ADCDIFF_KIND_OTHER, Tp, H, 0, 0.0, (double)Tp * H * 12.0, st);
+                hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)(((long)Tp * H + 255) / 256)), dim3(256), 0, st, n->te_table, d_s, d_te, (long)Tp * H);
+                TRY(check_launch("silu_bwd"));
+            }
         }
-        float* d_te = (float*)ws.take((size_t)Tp * H * 4);
-        if (!dry) {
-            TimingScope ts(ADCDIFF_KIND_OTHER, Tp, H, 0, 0.0, (double)Tp * H * 12.0, st);
-            hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)(((long)Tp * H + 255) / 256)), dim3(256), 0, st, n->te_table, d_s, d_te, (long)Tp * H);
-            TRY(check_launch("silu_bwd"));
+        if (cond || dry) {
+            // d(z) = d(s) * silu'(z), z = t_emb[t] + c_emb: its rows are scatter-added into the table gradient (the time MLP's
+            // backward below) and are the gradient of c_emb (condition_embed's backward here, diffusion_model.py:694-698)
+            ws.off = tail;
+            const int D = n->D;
+            float* d_z = (float*)ws.take((size_t)Bp * H * 4);
+            if (!dry && cond) {
+                if (hipMemsetAsync(d_te, 0, (size_t)Tp * H * 4, st) != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "unet_backward: memset failed");
+                TimingScope ts(ADCDIFF_KIND_OTHER, B, H, 0, 0.0, (double)B * H * 16.0, st);
+                const long total = (long)B * H;
+                hipLaunchKernelGGL(cond_silu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n->te_table, H, n->T, tp.t_rows, tp.cemb, H,
+                                   d_s_rows, d_z, B, H);
+                hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_z, (long)H, tp.t_rows, B, H, d_te, (long)H, 0, n->T);
+                TRY(check_launch("cond_silu_bwd"));
+            }
+            float* d_hid = (float*)ws.take((size_t)Bp * H * 4);
+            float* d_cpre = (float*)ws.take((size_t)Bp * H * 4);
+            void* dz_rm = ws.take((size_t)Bp * H * e);
+            const bool run = cond && !dry;
+            if (direct) {
+                if (run) TRY(cast_rows(d_z, H, B, Bp, H, dz_rm, H, gr->cond2_b, nullptr, st));
+                TRY(gemm_dw_direct(dz_rm, H, tp.c_hid, H, H, H, B, gr->cond2_w, H, H, ws, !run, st));
+                if (run) {
+                    TRY(gemm_tr(false, dz_rm, H, n->w_c2, H, d_hid, H, Bp, H, H, 1, 0, st));
+                    TRY(silu_bwd(tp.c_pre, d_hid, d_cpre, (long)B * H, st));
+                    TRY(cast_rows(d_cpre, H, B, Bp, H, dz_rm, H, gr->cond0_b, nullptr, st));
+                }
+                TRY(gemm_dw_direct(dz_rm, H, tp.c_op, D, H, D, B, gr->cond0_w, D, D, ws, !run, st));
+            } else {
+                void* dz_t = ws.take((size_t)H * Bp * e);
+                void* xT = ws.take((size_t)(D > H ? D : H) * Bp * e);
+                void* wT = ws.take((size_t)H * H * e);
+                if (run) {
+                    TRY(cast_transpose<float>(d_z, H, B, Bp, H, dt, dz_rm, H, dz_t, Bp, gr->cond2_b, st));
+                    TRY(transpose_op(tp.c_hid, H, B, Bp, H, dt, xT, st));
+                }
+                TRY(gemm_dw(dt, dz_t, xT, H, H, Bp, gr->cond2_w, ws, !run, st));
+                if (run) {
+                    TRY(cast_transpose<float>(p.cond2_w, H, H, H, H, dt, nullptr, 0, wT, H, nullptr, st));
+                    TRY(gemm_simple(dt, dz_rm, H, wT, H, Bp, B, H, H, d_hid, H, st));
+                    TRY(silu_bwd(tp.c_pre, d_hid, d_cpre, (long)B * H, st));
+                    TRY(cast_transpose<float>(d_cpre, H, B, Bp, H, dt, dz_rm, H, dz_t, Bp, gr->cond0_b, st));
+                    TRY(transpose_op(tp.c_op, D, B, Bp, D, dt, xT, st));
+                }
+                TRY(gemm_dw(dt, dz_t, xT, H, D, Bp, gr->cond0_w, ws, !run, st));
+            }
         }
+        ws.off = tail;
         float* dTE_t = (float*)ws.take((size_t)H * Tp * 4);
         RUN(cast_transpose<float>(d_te, H, Tp, Tp, H, ADCDIFF_F32, nullptr, 0, dTE_t, Tp, gr->time_lin2_b, st));
         float* hidT = (float*)ws.take((size_t)4 * H * Tp * 4);

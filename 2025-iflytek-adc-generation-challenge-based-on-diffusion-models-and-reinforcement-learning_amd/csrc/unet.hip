@@ -299,6 +299,7 @@ int adcdiff::forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, co
     void* a = ws.take((size_t)Bp * H * e);
     if (tape) {
         tape->a_out = a; tape->B = B; tape->t_rows = t_rows; tape->drop_p = drop_p; tape->drop_seed = drop_seed;
+        tape->s_op = cond ? s_op : nullptr;
         tape->valid = !dry;
     }
     if (!dry) {

@@ -83,6 +83,15 @@ struct Tape {
     BlockTape blk[10];
     const void* a_out = nullptr;   // SiLU(output_norm(decoder.3 output)) in the operand type
     size_t ws_used = 0;
+    // a conditional training forward (per-row condition): the condition in the operand type [Bp, D], condition_embed's hidden
+    // pre-activation (float32) and activation (operand type) [Bp, H], its output c_emb (float32 [Bp, H]) and
+    // s = SiLU(t_emb[t] + c_emb) in the operand type [Bp, H], which every block's time_proj consumes
+    bool cond = false;
+    const void* c_op = nullptr;
+    const float* c_pre = nullptr;
+    const void* c_hid = nullptr;
+    const float* cemb = nullptr;
+    const void* s_op = nullptr;
 };
 
 }  // namespace adcdiff

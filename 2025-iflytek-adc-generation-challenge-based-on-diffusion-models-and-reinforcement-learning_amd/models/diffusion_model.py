@@ -266,11 +266,18 @@ def _grad_slots(model):
             slots += [(b.residual_proj.weight, (i, "residual_w")), (b.residual_proj.bias, (i, "residual_b"))]
     slots += [(model.output_norm.weight, ("out_norm_w",)), (model.output_norm.bias, ("out_norm_b",)),
               (model.output_layer.weight, ("out_w",)), (model.output_layer.bias, ("out_b",))]
+    # last: written (and handed to autograd) only by a conditional loss; the reference's train_step never passes a condition
+    slots += [(model.condition_embed[0].weight, ("cond0_w",)), (model.condition_embed[0].bias, ("cond0_b",)),
+              (model.condition_embed[2].weight, ("cond2_w",)), (model.condition_embed[2].bias, ("cond2_b",))]
     return slots
 
 
-def _taped_forward_loss(model, x_noisy, t, noise, dropout_p, dropout_seed):
-    """Training-mode denoiser forward (dropout from the counter RNG) + mse_loss(noise, prediction) in the HIP library.
+_N_COND_SLOTS = 4
+
+
+def _taped_forward_loss(model, x_noisy, t, noise, dropout_p, dropout_seed, condition=None):
+    """Training-mode denoiser forward (dropout from the counter RNG; condition: None or [B, input_dim] rows whose
+    condition_embed joins the time embedding) + mse_loss(noise, prediction) in the HIP library.
     Returns (loss, d_eps, engine, handle, workspace tensor, generation): the activations the backward pass needs stay
     in the engine's workspace until the next call that uses it (which bumps the generation)."""
     dev = model._device()
@@ -278,7 +285,7 @@ def _taped_forward_loss(model, x_noisy, t, noise, dropout_p, dropout_seed):
     handle = eng.ensure(dev)
     B = x_noisy.shape[0]
     eng.train_workspace_for(B, dev)
-    eps = torch.ops.adcdiff.unet_train_forward(handle.value, x_noisy, t, float(dropout_p), int(dropout_seed), model.output_dim, eng.workspace)
+    eps = torch.ops.adcdiff.unet_train_forward(handle.value, x_noisy, t, condition, float(dropout_p), int(dropout_seed), model.output_dim, eng.workspace)
     loss, d_eps = torch.ops.adcdiff.mse_loss_grad(eps, noise, 1.0)
     return loss, d_eps, eng, handle, eng.workspace, eng.generation
 
@@ -291,10 +298,11 @@ class _NoisePredictionLoss(torch.autograd.Function):
     a forward()), instead of differentiating through the wrong activations."""
 
     @staticmethod
-    def forward(ctx, model, x_noisy, t, noise, dropout_p, dropout_seed, *params):
-        loss, d_eps, eng, handle, ws_tensor, generation = _taped_forward_loss(model, x_noisy, t, noise, dropout_p, dropout_seed)
+    def forward(ctx, model, x_noisy, t, noise, dropout_p, dropout_seed, condition, *params):
+        loss, d_eps, eng, handle, ws_tensor, generation = _taped_forward_loss(model, x_noisy, t, noise, dropout_p, dropout_seed, condition)
         ctx.model, ctx.eng, ctx.handle, ctx.d_eps, ctx.t = model, eng, handle, d_eps, t
-        ctx.inputs = (x_noisy, t, noise)     # the tape points at x_noisy and t: they must outlive the forward call
+        ctx.conditional = condition is not None
+        ctx.inputs = (x_noisy, t, noise, condition)     # the tape points at x_noisy and t: they must outlive the forward call
         ctx.ws_tensor = ws_tensor            # keeps the buffer alive even if the engine re-allocates a larger one
         ctx.generation = generation
         ctx.version = eng._param_version()
@@ -337,12 +345,14 @@ class _NoisePredictionLoss(torch.autograd.Function):
         # optimizer work on one flat buffer -- such .grad tensors are overwritten by the next backward.  Every other caller
         # of p_losses gets views of a private copy that nothing overwrites.
         src = flat if model.alias_gradients else flat.clone()
+        live = slots if ctx.conditional else slots[:-_N_COND_SLOTS]   # condition_embed has a gradient only under a conditional loss
         fresh, off = {}, 0
-        for p, _ in slots:
+        for p, _ in live:
             fresh[id(p)] = src[off:off + p.numel()].view_as(p)
             off += (p.numel() + 3) // 4 * 4
+        model._grad_live = len(live)
         out = [fresh.get(id(p)) if p.requires_grad else None for p in params]
-        return (None, None, None, None, None, None) + tuple(out)
+        return (None, None, None, None, None, None, None) + tuple(out)
 
 
 class UNetModel(nn.Module):
@@ -410,7 +420,7 @@ class UNetModel(nn.Module):
         flat, views = self._grad_flat
         ptrs = {v.data_ptr() for v in views}
         have = [p for p in self.parameters() if p.grad is not None]
-        if have and all(p.grad.data_ptr() in ptrs for p in have) and len(have) == len(views):
+        if have and all(p.grad.data_ptr() in ptrs for p in have) and len(have) == getattr(self, "_grad_live", len(views)):
             return flat
         return None
 
@@ -631,25 +641,29 @@ class DiffusionModel(nn.Module):
     def p_losses(self, x_start: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None,
                  noise: Optional[torch.Tensor] = None, row_offset: int = 0) -> torch.Tensor:
         """diffusion_model.py:165-184.  With gradients enabled the returned loss back-propagates through the HIP
-        backward kernels (unconditional, as in the reference's train_step).  Dropout follows self.model.training with and
-        without gradients.  row_offset keys the counter-RNG noise by global row (data-parallel training)."""
+        backward kernels, with a condition also into condition_embed (:764-766).  Dropout follows self.model.training with
+        and without gradients, with and without a condition.  row_offset keys the counter-RNG noise by global row
+        (data-parallel training)."""
         dv = self._device_tables()
         x_noisy, used = ops.q_sample(x_start.to(torch.float32).contiguous(), t.to(torch.int64).contiguous(), dv["sqrt_ac"],
                                      dv["sqrt_1mac"], noise=noise.contiguous() if noise is not None else None,
                                      seed=_seed_from_torch() if noise is None else 0, row_offset=row_offset, return_noise=True)
         wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters())
         drop_p = self.model.encoder[0].dropout.p if self.model.training else 0.0
-        if not wants_grad and (condition is not None or drop_p == 0.0):
+        B = x_start.shape[0]
+        if condition is not None:
+            # per-row conditions for the taped forward: a [D] or [1, D] condition broadcasts over the batch, as t_emb + c_emb does (:766)
+            condition = self.model.expand_condition(condition, B).to(device=x_noisy.device, dtype=torch.float32)
+            condition = condition.expand(B, -1).contiguous()
+        if not wants_grad and drop_p == 0.0:
             predicted_noise = self.model(x_noisy, t, condition)
             return torch.ops.adcdiff.mse_loss_grad(predicted_noise, used, 1.0)[0]   # the same kernel as the differentiable path
-        if condition is not None:
-            raise NotImplementedError("the backward kernels cover the unconditional loss of train_step; a condition has no gradient path yet")
         rank, _ = _dp_rank_world()
         drop_seed = (_seed_from_torch() + rank) if drop_p > 0 else 0     # ranks seeded alike still draw different masks
         t64 = t.to(torch.int64).contiguous()
         if not wants_grad:   # value only, train mode: the taped forward with dropout, no backward
-            return _taped_forward_loss(self.model, x_noisy, t64, used, drop_p, drop_seed)[0]
-        return _NoisePredictionLoss.apply(self.model, x_noisy, t64, used, drop_p, drop_seed, *self.model.parameters())
+            return _taped_forward_loss(self.model, x_noisy, t64, used, drop_p, drop_seed, condition)[0]
+        return _NoisePredictionLoss.apply(self.model, x_noisy, t64, used, drop_p, drop_seed, condition, *self.model.parameters())
 
     # ---- reverse process --------------------------------------------------------------------
     def p_sample(self, x: torch.Tensor, t: torch.Tensor, condition: Optional[torch.Tensor] = None,

@@ -204,18 +204,21 @@ def _(handle, x_T, cemb, timesteps, coef, noise, seed, row_offset, ws):
 
 
 @_op("adcdiff::unet_train_forward", mutates_args=("ws",))
-def unet_train_forward(handle: int, x: Tensor, t: Tensor, dropout_p: float, dropout_seed: int, output_dim: int, ws: Tensor) -> Tensor:
-    """Training-mode forward with per-row timesteps; leaves the activations the backward pass needs in ws."""
+def unet_train_forward(handle: int, x: Tensor, t: Tensor, cond: Optional[Tensor], dropout_p: float, dropout_seed: int, output_dim: int,
+                       ws: Tensor) -> Tensor:
+    """Training-mode forward with per-row timesteps (and, optionally, per-row conditions [B, input_dim]); leaves the activations the
+    backward pass needs in ws."""
     B = x.shape[0]
     eps = torch.empty((B, output_dim), device=x.device, dtype=torch.float32)
     p, n = _ws(ws)
-    check(_lib.load().adcdiff_unet_train_forward(_h(handle), ops._ptr(x), x.stride(0), B, ops._ptr(t), dropout_p, dropout_seed, ops._ptr(eps),
-                                                 output_dim, p, n, ops._stream()))
+    check(_lib.load().adcdiff_unet_train_forward(_h(handle), ops._ptr(x), x.stride(0), B, ops._ptr(t), ops._ptr(cond) if cond is not None else None,
+                                                 cond.stride(0) if cond is not None else 0, dropout_p, dropout_seed, ops._ptr(eps), output_dim, p, n,
+                                                 ops._stream()))
     return eps
 
 
 @unet_train_forward.register_fake
-def _(handle, x, t, dropout_p, dropout_seed, output_dim, ws):
+def _(handle, x, t, cond, dropout_p, dropout_seed, output_dim, ws):
     return x.new_empty((x.shape[0], output_dim))
 
 

@@ -243,7 +243,8 @@ int adcdiff_ddim_sample_loop(adcdiff_unet* net, float* x, int ldx, int B, const 
 
 /* Gradient destinations, float32, same shapes as the parameters of adcdiff_unet_params.  Bias and GroupNorm
  * gradients are ACCUMULATED with atomics and must be zero on entry; weight gradients are overwritten.
- * condition_embed takes no gradient (the reference's train_step never passes a condition, diffusion_model.py:427,450). */
+ * The condition_embed gradients (cond*) are written only after a conditional training forward (p_losses with a condition,
+ * diffusion_model.py:165-184 with :764-766); the reference's train_step itself never passes one (:427, :450). */
 typedef struct adcdiff_block_grads {
     float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
     float *linear1_w, *linear1_b, *linear2_w, *linear2_b;
@@ -254,6 +255,7 @@ typedef struct adcdiff_unet_grads {
     float *time_lin1_w, *time_lin1_b, *time_lin2_w, *time_lin2_b;
     adcdiff_block_grads blocks[10];
     float *out_norm_w, *out_norm_b, *out_w, *out_b;
+    float *cond0_w, *cond0_b, *cond2_w, *cond2_b;
 } adcdiff_unet_grads;
 
 /* Workspace for one training forward + backward at this batch (activations stay in it between the two calls). */
@@ -262,9 +264,12 @@ size_t adcdiff_unet_train_workspace_bytes(int input_dim, int hidden_dim, int out
 /* UNetModel.forward in training mode (diffusion_model.py:749-789 under model.train(), :413) with per-row timesteps:
  * dropout(p) after the norm2 activation of every ResidualBlock (:898) from the counter RNG (dropout_seed, layer, row,
  * column); leaves the activations the backward pass needs in the workspace.  Requires adcdiff_unet_pack after the last
- * parameter change (the timestep tables are part of the differentiated graph). */
-int adcdiff_unet_train_forward(adcdiff_unet* net, const float* x, int ldx, int B, const int64_t* t_rows, float dropout_p,
-                               uint64_t dropout_seed, float* eps, int lde, void* workspace, size_t workspace_bytes,
+ * parameter change (the timestep tables are part of the differentiated graph).
+ * cond: NULL, or the condition rows [B, input_dim] float32 (leading dimension ldc): condition_embed (:694-698) runs inside the
+ * call and its output joins the time embedding of every row (:764-766); adcdiff_unet_backward then also produces the
+ * condition_embed gradients. */
+int adcdiff_unet_train_forward(adcdiff_unet* net, const float* x, int ldx, int B, const int64_t* t_rows, const float* cond, int ldc,
+                               float dropout_p, uint64_t dropout_seed, float* eps, int lde, void* workspace, size_t workspace_bytes,
                                adcdiff_stream_t stream);
 
 /* F.mse_loss(target, pred) with mean reduction (diffusion_model.py:183): *loss_accum += scale * mean((target - pred)^2),

@@ -152,8 +152,9 @@ def test_large_batch_gradient_is_mean_of_half_batch_gradients(dtype):
         assert float((ga - ref).abs().max()) <= tol * max(float(ref.abs().max()), 1e-6), k
 
 
+@pytest.mark.parametrize("conditional", [False, True])
 @pytest.mark.parametrize("dims,B", [((128, 128, 128), 64), ((512, 256, 512), 1024)])
-def test_backward_without_transposed_copies_gives_the_same_gradients(dims, B, monkeypatch):
+def test_backward_without_transposed_copies_gives_the_same_gradients(dims, B, conditional, monkeypatch):
     """bf16 batches that are multiples of 64 run the backward GEMMs on the stored operands (adcdiff_gemm_tr); the NT
     kernel on transposed copies (debug switch train_transpose = 1, and every other batch size or float32) must give the same
     weight gradients bit for bit: same MFMA, same k order, same slicing of the batch contraction.  Dropout active."""
@@ -165,12 +166,13 @@ def test_backward_without_transposed_copies_gives_the_same_gradients(dims, B, mo
     x = torch.randn(B, dims[0], generator=gen).cuda()
     nz = torch.randn(B, dims[0], generator=gen).cuda()
     t = torch.randint(0, 1000, (B,), generator=gen).cuda()
+    cond = torch.randn(B, dims[0], generator=gen).cuda() if conditional else None
 
     def grads(transpose):
         adcdiff._lib.debug_set("train_transpose", 1 if transpose else 0)
         m.model.zero_grad(set_to_none=True)
         torch.manual_seed(3)             # the dropout seed is drawn from torch: same masks in both passes
-        loss = m.p_losses(x, t, noise=nz)
+        loss = m.p_losses(x, t, cond, noise=nz)
         loss.backward()
         torch.cuda.synchronize()
         return {k: p.grad.clone() for k, p in m.model.named_parameters() if p.grad is not None}
@@ -185,6 +187,9 @@ def test_backward_without_transposed_copies_gives_the_same_gradients(dims, B, mo
         assert torch.isfinite(direct[k]).all(), k
         if k.endswith(("linear1.weight", "linear2.weight", "residual_proj.weight", "output_layer.weight")) and not k.startswith("time_embed"):
             assert torch.equal(direct[k], copies[k]), k
+            exact += 1
+        elif conditional and k.endswith("weight") and ("time_proj" in k or "condition_embed" in k):
+            assert torch.equal(direct[k], copies[k]), k    # with a condition these are products over the batch rows like the others
             exact += 1
         elif "time" in k and k.endswith("weight"):
             # the time branch's large products run on bf16 copies of the table gradient in the direct path, float32 in the other
@@ -387,6 +392,32 @@ def test_public_p_losses_honours_the_autograd_contract():
     (m.p_losses(x[8:], t[8:], noise=nz[8:]) * 0.25).backward()
     g_w = next(g for p, g in zip(params, got) if p is w)
     assert torch.allclose(w.grad, 0.25 * g_w, rtol=1e-5, atol=1e-9)
+
+
+def test_conditional_loss_broadcasts_one_condition_and_drops_out_in_train_mode():
+    """A [D] or [1, D] condition is shared by the batch (as t_emb + c_emb broadcasts, diffusion_model.py:766) and equals the
+    repeated condition; under no_grad in train mode the conditional loss has dropout on, like the unconditional one."""
+    m = build("fp32")
+    x, t = cu(philox.normal(SEED, 52, 0, 0, 16, 128)), torch.arange(16, device="cuda") * 60
+    nz = cu(philox.normal(SEED, 53, 0, 0, 16, 128))
+    c1 = cu(philox.normal(SEED, 51, 0, 0, 1, 128))
+    m.model.eval()
+    la = m.p_losses(x, t, c1[0], noise=nz); la.backward()
+    ga = {k: p.grad.clone() for k, p in m.model.named_parameters() if p.grad is not None}
+    m.model.zero_grad(set_to_none=True)
+    lb = m.p_losses(x, t, c1.repeat(16, 1), noise=nz); lb.backward()
+    assert float(la.detach()) == float(lb.detach())
+    for k, p in m.model.named_parameters():
+        if p.grad is not None:
+            assert torch.allclose(ga[k], p.grad, rtol=1e-4, atol=1e-6 * float(p.grad.abs().max())), k
+    assert "condition_embed.0.weight" in ga and float(ga["condition_embed.0.weight"].abs().max()) > 0
+    with torch.no_grad():
+        e1 = float(m.p_losses(x, t, c1, noise=nz))
+        m.model.train()
+        torch.manual_seed(11); d1 = float(m.p_losses(x, t, c1, noise=nz))
+        torch.manual_seed(11); d2 = float(m.p_losses(x, t, c1, noise=nz))
+    # the value-only eval forward runs the fused kernels, the differentiable one the taped forward: equal to summation order
+    assert abs(e1 - float(la.detach())) < 1e-5 * e1 and d1 == d2 and abs(d1 - e1) > 1e-4 * e1
 
 
 def test_validation_loss_follows_training_mode():

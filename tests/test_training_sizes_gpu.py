@@ -33,6 +33,15 @@ GATES = {
 }
 
 
+# conditional loss p_losses(x, t, condition): loss, worst grad_rel over 12 tensors (condition_embed.{0,2}, time_embed, time_proj and
+# others), global norm.  Measured: fp32 0 / 1e-7 / 1e-7, 2.2e-5 / 6.0e-6 / 7.9e-5, 5e-7 / 2e-7 / 2.4e-5;
+# bf16 2.3e-4 / 1.3e-5 / 1.9e-4, 0.10 / 0.018 / 0.31, 1.5e-3 / 4.5e-4 / 6.4e-2
+COND_GATES = {
+    ("tiny_cond", "fp32"): (1e-6, 7e-5, 4e-6), ("train_a", "fp32"): (1e-6, 2e-5, 1e-6), ("train_b", "fp32"): (1e-6, 2.5e-4, 7e-5),
+    ("tiny_cond", "bf16"): (1e-3, 0.3, 5e-3), ("train_a", "bf16"): (2e-4, 6e-2, 1.5e-3), ("train_b", "bf16"): (6e-4, 0.9, 0.19),
+}
+
+
 def cu(a, dtype=torch.float32):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda").to(dtype)
 
@@ -122,3 +131,27 @@ def test_train_step_matches_the_reference_at_baseline_sizes(name, dtype, monkeyp
         assert (d < near).mean() >= gate[4] and d.max() <= gate[5], (k, float(d.max()), float((d < near).mean()))
         before = w0[k].ravel() if ("train_step_after." + k) in g.files else w0[k].ravel()[::int(g["train_step_after." + k + ".stride"])]
         assert np.abs(got - before).max() > 5e-5, k   # the step really moved the weights (lr = 1e-4)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_conditional_loss_backpropagates_into_condition_embed_like_the_reference(name, dtype):
+    """p_losses(x, t, condition) (diffusion_model.py:165-184 with :764-766): value, the gradients of condition_embed and of
+    layers the condition reaches through time_proj and the time embedding, and the global norm, against the reference."""
+    g, dims = load_golden(name), CASES[name]
+    gate = COND_GATES[(name, dtype)]
+    B, D = g["x0"].shape
+    m = build(dims, dtype)
+    m.model.eval()
+    nz = cu(philox.normal(SEED, philox.STREAM_QNOISE, 0, 0, B, D))
+    loss = m.p_losses(cu(g["x0"]), cu(g["t"], torch.int64), cu(g["cond"]), noise=nz)
+    assert abs(float(loss.detach()) - float(g["cond.p_losses"])) <= gate[0] * float(g["cond.p_losses"])
+    loss.backward()
+    grads = {k: p.grad for k, p in m.model.named_parameters() if p.grad is not None}
+    assert all(("condition_embed.%d.%s" % (i, w)) in grads for i in (0, 2) for w in ("weight", "bias"))
+    rel, l2 = grad_errors(g, "cond.grad.", grads)
+    assert len(rel) >= 12
+    print("conditional training parity %s %s: worst grad_rel %.2e (%s)" % (name, dtype, max(rel.values()), max(rel, key=rel.get)))
+    assert max(rel.values()) <= gate[1], rel
+    sq = sum(float((p.double() ** 2).sum()) for p in grads.values())
+    assert abs(np.sqrt(sq) - float(g["cond.grad_global_norm"])) <= gate[2] * float(g["cond.grad_global_norm"])
