@@ -26,7 +26,8 @@ class GemmArgs(C.Structure):
                 ("bias", c_fp), ("rowbias", c_fp), ("ldrb", C.c_longlong), ("rowbias_idx", c_fp), ("rowbias_rows", C.c_int),
                 ("residual", c_fp), ("ldr", C.c_int), ("act", C.c_int), ("out_f32", c_fp), ("ldo_f32", C.c_int),
                 ("out_op", c_fp), ("ldo_op", C.c_int), ("n_gn", C.c_int), ("gn", GnOut * 2), ("gn_eps", C.c_float), ("tile_hint", C.c_int),
-                ("split_k", C.c_int), ("split_stride", C.c_longlong), ("update", StepUpdate)]
+                ("split_k", C.c_int), ("split_stride", C.c_longlong), ("update", StepUpdate),
+                ("splitk_scratch", c_fp), ("splitk_scratch_bytes", C.c_longlong)]
 
 
 class DdpmCoef(C.Structure):

@@ -390,10 +390,10 @@ const DebugEntry kDebug[DBG_NKEYS] = {
     {"gemm_w1", 1},           // 0: the tile kernels instead of the one-wave kernels for few live rows
     {"gemm_w1_rows", 1024},   // live rows up to which the one-wave kernels are taken
     {"gemm_cl", 1},           // 0: never the loader-wave variant of the one-wave kernel
+    {"gemm_splitk", 1},       // 0: never the few-row kernel that splits K over workgroups (results then bit-identical to the tile kernels)
     {"step_fold", 1},         // 0: the reverse step as a launch of its own instead of the output GEMM's epilogue
     {"train_transpose", 0},   // 1: backward products on transposed copies (the NT kernel) instead of gemm_tr
     {"sync", 0},              // 1: synchronise and check after every training launch
-    {"raster", 0},            // workgroup -> tile order of the four-wave kernel (0 = shipped)
 };
 std::atomic<long long> g_debug[DBG_NKEYS];
 std::atomic<bool> g_debug_init{false};

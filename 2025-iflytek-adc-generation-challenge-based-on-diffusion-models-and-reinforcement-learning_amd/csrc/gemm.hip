@@ -59,6 +59,9 @@ struct GemmParams {
     int ksplit;                  // grid.y: K slices (1 without split-K)
     long long split_k_bytes;     // byte offset along K of slice blockIdx.y (0 without split-K)
     long long split_out_stride;  // floats between the partial outputs of consecutive slices
+    int sk_splits;               // few-row split-K kernel: workgroups per output tile (0 = not used)
+    float* sk_part;              // its partial accumulators, [tiles][sk_splits][TM * TN][64 lanes][4] floats
+    unsigned* sk_cnt;            // its arrival counters, one per output tile; zero before and after every launch
 #ifdef ADCDIFF_STAMPS
     long long* stamps;
 #endif
@@ -1522,6 +1525,194 @@ static int launch_w1(const GemmParams& p, hipStream_t stream) {
     return check_launch("gemm (one wave per tile)");
 }
 
+// ---- the one-wave tile with K split over workgroups: launches with at most BM live rows (the generator's batch of 32) ----------------
+// A layer at such a batch is its weight matrix streamed once: N / BN one-wave workgroups (8 to 32 of them) each pull BN rows of W
+// through ONE CU, and a CU gets about 48 GB/s of lines from beyond its L2 whatever the loop around the loads.  Here every output tile
+// has S workgroups, each with a contiguous range of at most D K tiles: a workgroup issues ALL its LDS-DMA pieces at once (at most 63,
+// the vmcnt counter), multiplies, and writes its partial accumulators (raw MFMA layout, 1 KiB per store instruction) to a scratch
+// buffer; one atomic increment per workgroup on the tile's counter decides who arrived last, and that
+// workgroup adds the S partials IN SPLIT ORDER (its own from memory as well, so the sum does not depend on who was last), resets
+// the counter and runs the shared epilogue.  The K order differs from the other kernels' (S partial sums instead of one chain), so
+// the result is NOT bit-identical to theirs: it is deterministic, and equal to them up to float32 summation order.
+template <int BM, int BN>
+__global__ __launch_bounds__(64) void gemm_w1s_bf16_kernel(const GemmParams p) {
+    typedef bf16_t T;
+    constexpr int TM = BM / 16, TN = BN / 16;
+    constexpr int AP = BM / 8, WP = BN / 8, P = AP + WP;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int D = 57 / P < 8 ? 57 / P : 8;                 // tiles per round: their pieces and six more loads fit the vmcnt counter
+    constexpr int NM = 2 * TM * TN, NR = 2 * (TM + TN);
+    typedef Epilogue<T, 64, BN, BM, BN, TM, TN> Epi;
+    constexpr int MAIN_BYTES = D * STAGE_BYTES > Epi::STAGE_BYTES ? D * STAGE_BYTES : Epi::STAGE_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const prm = reinterpret_cast<float*>(smem + MAIN_BYTES);
+    float* const xch = prm + 5 * BN;
+    const int lane = threadIdx.x;
+    const int S = p.sk_splits;
+    // workgroup -> (tile, split): the S workgroups of a tile on ONE XCD (consecutive workgroup ids go round the eight XCDs), so that
+    // the last one finds the others' partials in its own L2; any other tile count takes the plain order (the fences do not care)
+    int tile, sp;
+    {
+        const int b = (int)blockIdx.x;
+        if ((p.ntn & 7) == 0) { const int j = b >> 3; sp = j % S; tile = (j / S) * 8 + (b & 7); }
+        else { tile = b / S; sp = b % S; }
+    }
+    const int m0 = 0, n0 = tile * BN;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int nt = p.nt_total;
+    const int t0 = (int)((long)sp * nt / S), t1 = (int)((long)(sp + 1) * nt / S);   // this workgroup's K tiles
+
+    auto make_srd = [](unsigned long long base, unsigned bytes) {
+        return i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)base), __builtin_amdgcn_readfirstlane((int)((unsigned)(base >> 32) & 0xffffu)),
+                     __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+    };
+    const unsigned ldw_b = (unsigned)p.ldw * 2u;
+    const i32x4 srd_w = make_srd((unsigned long long)p.W + (unsigned long long)n0 * ldw_b, (unsigned)(BN - 1) * ldw_b + (unsigned)nt * 128u);
+    int voff[P];
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+        const int row = 8 * j + (lane >> 3);
+        voff[AP + j] = (int)((unsigned)row * ldw_b + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16)) - 1024 * ((AP + j) & 3);
+    }
+    i32x4 srd_a;
+    auto enter_segment = [&](int sg) {
+        const unsigned ld = (unsigned)p.lda[sg] * 2u;
+        srd_a = make_srd((unsigned long long)p.A[sg] + (unsigned long long)m0 * ld, (unsigned)(BM - 1) * ld + (unsigned)p.ktiles[sg] * 128u);
+#pragma unroll
+        for (int j = 0; j < AP; ++j) {
+            const int row = 8 * j + (lane >> 3);
+            voff[j] = (int)((unsigned)row * ld + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16)) - 1024 * (j & 3);
+        }
+    };
+    // the K segment that holds tile t0 (t0 < nt = the sum of the segments' tiles, so the walk ends inside the segments)
+    int seg = 0, tt = t0;
+    while (seg < 2 && tt >= p.ktiles[seg]) { tt -= p.ktiles[seg]; ++seg; }
+    enter_segment(seg);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int frow = lane & 15, fchunk = lane >> 4;
+    // rounds of at most D tiles: all pieces of a round go out at once (at most 57 loads in flight, plus the epilogue's column
+    // vectors in the first round: the vmcnt counter holds 63), then the round's tiles are multiplied.  Nothing overlaps a
+    // round's loads with the previous round's MFMAs: a workgroup has a handful of tiles and its time is one or two memory
+    // latencies either way.
+    int it = t0;
+    bool first = true;
+    while (it < t1) {
+        const int nround = t1 - it < D ? t1 - it : D;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            if (k < nround) {   // wave-uniform
+                if (tt == p.ktiles[seg]) {
+                    ++seg; tt = 0;
+                    if (seg < 2 && tt == p.ktiles[seg]) ++seg;
+                    enter_segment(seg);
+                }
+                const int soa = tt * 128, sow = it * 128;
+#pragma unroll
+                for (int m = 0; m < P; ++m) dma_piece(m, voff[m], m < AP ? srd_a : srd_w, m < AP ? soa : sow, lds0 + k * STAGE_BYTES);
+                ++tt; ++it;
+            }
+        }
+        if (first) Epi::stage_params(p, n0, lane, prm);   // younger than every piece of the round
+        first = false;
+        wait_vmcnt<0>();
+        for (int t = 0; t < nround; ++t) {
+            const char* const stage = smem + t * STAGE_BYTES;
+            uint4 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                const int ks = m / (TM + TN), r = m % (TM + TN);
+                const int c = 4 * ks + fchunk;
+                const int row = (r < TM ? r : r - TM) * 16 + frow;
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + (r < TM ? 0 : BM * 128) + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                if (r < TM) fa[ks][r] = v; else fb[ks][r - TM] = v;
+            }
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int ks = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks][i]), __builtin_bit_cast(bf16x8, fb[ks][j]), acc[i][j], 0, 0, 0);
+            }
+        }
+        // the round's fragment reads have returned (the MFMAs consumed them) before the next round's pieces overwrite the stages
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    // partial accumulators out, arrival count up; the last workgroup of the tile sums all S partials in split order.
+    // The exchange goes THROUGH the caches instead of flushing them: the partials are stored and loaded as relaxed system-scope
+    // atomics (write-through to / read from the memory side, 256 contiguous bytes per instruction), the stores are waited for
+    // (vmcnt) before the lane-0 increment, which is performed at the memory side as well.  A device-scope fence pair here
+    // (an L2 write-back and invalidate per workgroup) cost 6 us per launch, more than the split gains.
+    // (Device scope for the partials, which the same-XCD placement would allow, measured the same.)
+    auto exchange = [&](auto SCOPE) {
+        constexpr int SC = decltype(SCOPE)::value;
+        float* const mine = p.sk_part + (((size_t)tile * S + sp) * (TM * TN * 4)) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < TM * TN; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                __hip_atomic_store(mine + (k * 4 + c) * 64, acc[k / TN][k % TN][c], __ATOMIC_RELAXED, SC);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every lane's partials have reached the coherence point
+        unsigned arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+        if (arrived != (unsigned)(S - 1)) return false;
+        const float* const all = p.sk_part + ((size_t)tile * S * (TM * TN * 4)) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < TM * TN; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[k / TN][k % TN][c] = __hip_atomic_load(all + (k * 4 + c) * 64, __ATOMIC_RELAXED, SC);
+        // up to four splits' loads in flight at a time (128 registers), added in split order
+        constexpr int U = 32 / (TM * TN) >= 4 ? 4 : 32 / (TM * TN) >= 1 ? 32 / (TM * TN) : 1;
+        for (int q = 1; q < S; q += U) {
+            float v[U][TM * TN * 4];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (q + u < S) {
+                    const float* const src = all + (size_t)(q + u) * (TM * TN * 4) * 64;
+#pragma unroll
+                    for (int k = 0; k < TM * TN * 4; ++k) v[u][k] = __hip_atomic_load(src + k * 64, __ATOMIC_RELAXED, SC);
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (q + u < S) {
+#pragma unroll
+                    for (int k = 0; k < TM * TN * 4; ++k) acc[(k / 4) / TN][(k / 4) % TN][k & 3] += v[u][k];
+                }
+        }
+        if (lane == 0) __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // for the next launch
+        return true;
+    };
+    if (!exchange(std::integral_constant<int, __HIP_MEMORY_SCOPE_SYSTEM>{})) return;
+    Epi::template run<true, (BN >= 64 ? 4 : 2)>(acc, p, m0, n0, 0, 0, 0, lane, reinterpret_cast<float*>(smem), prm, xch);
+}
+
+constexpr int w1s_tiles(int bm, int bn) { return 57 / ((bm + bn) / 8) < 8 ? 57 / ((bm + bn) / 8) : 8; }
+
+template <int BM, int BN>
+static int launch_w1s(const GemmParams& p, int splits, hipStream_t stream) {
+    typedef Epilogue<bf16_t, 64, BN, BM, BN, BM / 16, BN / 16> Epi;
+    constexpr int D = w1s_tiles(BM, BN);
+    constexpr int main_bytes = D * (BM + BN) * 128 > Epi::STAGE_BYTES ? D * (BM + BN) * 128 : Epi::STAGE_BYTES;
+    constexpr int smem = main_bytes + Epi::EXTRA_BYTES;
+    static_assert(smem <= 160 * 1024, "LDS of a CU");
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w1s_bf16_kernel<BM, BN>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    GemmParams q = p;
+    q.ntn = p.N / BN;
+    q.sk_splits = splits;
+    (void)D;
+    if (p.m_valid > BM || splits < 2 || splits > p.nt_total)
+        return fail(ADCDIFF_E_BADARG, "gemm: split-K geometry (rows %d > %d, %d splits of %d K tiles)", p.m_valid, BM, splits, p.nt_total);
+    hipLaunchKernelGGL((gemm_w1s_bf16_kernel<BM, BN>), dim3(q.ntn * splits), dim3(64), smem, stream, q);
+    return check_launch("gemm (one wave per tile, K split over workgroups)");
+}
+
 // ---- the same tile with loader waves: wave 0 reads fragments, multiplies and runs the epilogue, waves 1 .. P / 4 issue the LDS-DMA --
 // The lone wave above issues all 8 to 24 pieces of a tile between its MFMAs.  Here every group of four pieces (one M0 write) has a
 // wave of its own with its
@@ -1904,7 +2095,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     const bool w1_default = debug_value(DBG_GEMM_W1) != 0;
     // up to 1024 rows (16 row tiles of 64): 12 % less time per sampling step than the 128-row tile kernels at batches of 128 to 1024
     const int w1_rows = (int)debug_value(DBG_GEMM_W1_ROWS);
-    if (a.dtype == ADCDIFF_BF16 && p.m_valid >= 1 && p.ksplit == 1 && (a.tile_hint == 0 || a.tile_hint == 32 || a.tile_hint == 325)) {
+    if (a.dtype == ADCDIFF_BF16 && p.m_valid >= 1 && p.ksplit == 1 && (a.tile_hint == 0 || a.tile_hint == 32 || a.tile_hint == 325 || a.tile_hint == 327)) {
         int gmax = 0;
         for (int g = 0; g < a.n_gn; ++g) gmax = a.gn[g].group_size > gmax ? a.gn[g].group_size : gmax;
         const int bn = gmax <= 32 ? 32 : gmax <= 64 ? 64 : 128;
@@ -1920,6 +2111,28 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         // with 32 columns it loses.  325 = that variant wherever it exists, 32 = never (measurement aids)
         const bool cl_default = debug_value(DBG_GEMM_CL) != 0;
         if (take && a.N % bn == 0) {
+            // at most 64 live rows and a scratch buffer from the caller: K split over workgroups, S per output tile, so that the
+            // layer's weights stream through (about) every CU instead of N / bn of them.  S: enough for 256 workgroups, at least
+            // two K tiles each, at most what one workgroup can hold in flight, and what the scratch buffer holds.
+            // Where it pays (device time per launch at 32 rows, one-wave / loader-wave kernel against this one): the layers that
+            // stream at least 4 MB of weights through tiles of 32 or 64 columns -- N = K = 2048 12.4 -> 10.3 us, N = 1024 with
+            // K = 4096 / 5120 14.9 -> 9.3 / 21.5 -> 14.6 us; it loses about 1 us on the small layers (the exchange) and changes
+            // nothing for the 128-column tiles (22 us either way); tile_hint 327 forces it.
+            const bool pays = bn <= 64 && p.nt_total >= 32 && (long long)a.N * ktot >= (1LL << 22);
+            if (a.splitk_scratch && p.m_valid <= 64 && (a.tile_hint == 327 || (a.tile_hint == 0 && pays)) && debug_value(DBG_GEMM_SPLITK) != 0) {
+                const int bm = r32 ? 32 : 64, ntn = a.N / bn;
+                int S = 256 / ntn;
+                if (S > p.nt_total / 2) S = p.nt_total / 2;
+                if (S > 16) S = 16;
+                const long long need = 4096 + (long long)S * bm * a.N * 4;
+                if (S >= 2 && ntn <= 1024 && need <= a.splitk_scratch_bytes && aligned16(a.splitk_scratch)) {
+                    p.sk_cnt = reinterpret_cast<unsigned*>(a.splitk_scratch);
+                    p.sk_part = reinterpret_cast<float*>(reinterpret_cast<char*>(a.splitk_scratch) + 4096);
+                    if (bn == 32) return r32 ? launch_w1s<32, 32>(p, S, stream) : launch_w1s<64, 32>(p, S, stream);
+                    if (bn == 64) return r32 ? launch_w1s<32, 64>(p, S, stream) : launch_w1s<64, 64>(p, S, stream);
+                    return r32 ? launch_w1s<32, 128>(p, S, stream) : launch_w1s<64, 128>(p, S, stream);
+                }
+            }
             if (a.tile_hint == 325 || (a.tile_hint == 0 && cl_default)) {
                 if (bn == 32 && a.tile_hint == 325) return r32 ? launch_cl<32, 32>(p, stream) : launch_cl<64, 32>(p, stream);
                 // 64-row tiles: while every workgroup gets a CU of its own (their rings fill a CU's LDS; with 16 row tiles at

@@ -69,6 +69,12 @@ static void carve_arena(adcdiff_unet* n, void* arena, size_t cap) {
     n->s_cond = (float*)a.take((size_t)n->Tp * n->H * 4);
     n->tb_cond = (float*)a.take((size_t)n->Tp * n->sumN * 4);
     n->pack_table = (PackItem*)a.take(PACK_MAX_ITEMS * sizeof(PackItem));
+    // few-row GEMMs split K over workgroups through this buffer (adcdiff_gemm_args.splitk_scratch): arrival counters, zeroed by
+    // adcdiff_unet_pack and left zero by every launch, and the partial sums of 16 splits x 64 rows x the widest layer
+    int widest = n->O;
+    for (int i = 0; i < 10; ++i) widest = n->blk[i].cout > widest ? n->blk[i].cout : widest;
+    n->sk_bytes = 4096 + (size_t)16 * 64 * widest * 4;
+    n->sk_scratch = a.take(n->sk_bytes);
     n->arena_used = a.off;
 }
 
@@ -172,6 +178,7 @@ extern "C" int adcdiff_unet_pack(adcdiff_unet* n, void* workspace, size_t worksp
         n->pack_uploaded = true;
     }
     TRY(pack_items(n->pack_table, n->n_pack, n->pack_chunks, st));
+    if (hipMemsetAsync(n->sk_scratch, 0, 4096, st) != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "unet_pack: clearing the split-K counters failed");
 
     // TimeEmbedding(t) for every timestep (diffusion_model.py:802-823), float32 throughout
     if (!n->sin_built) TRY(sinusoid_table(n->sin_table, H, n->Tp, H / 2, p.sinusoid_freq, st));
@@ -351,6 +358,8 @@ int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t
         if (!dry) TRY(temb_silu(n->te_table, H, n->T, t_rows, t_uniform, cemb, ldce, dt, s, H, B, H, st));
         s_op = s;
     }
+    // at most 64 rows (the generator's batch is 32): the GEMMs may split K over workgroups through the plan's scratch buffer
+    void* const sk = B <= 64 ? n->sk_scratch : nullptr;
     // the latent enters through the one stand-alone GroupNorm of the step: encoder.0's norm1 (diffusion_model.py:888-889)
     Act in;
     void *in_nrm, *in_raw;
@@ -384,6 +393,7 @@ int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t
             }
             g.n_gn = 1; g.gn_eps = 1e-5f;
             g.gn[0] = adcdiff_gn_out{q.norm2_w, q.norm2_b, a2, b.cout, b.gs2};
+            g.splitk_scratch = sk; g.splitk_scratch_bytes = (long long)n->sk_bytes;
             TRY(gemm_dispatch(g, st));
         }
         // second GEMM: linear2 + residual, emitting what the consumers of this block's output read
@@ -413,6 +423,7 @@ int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t
                 g.gn[g.n_gn++] = adcdiff_gn_out{p.blocks[9 - i].norm1_w + db.part_c[0], p.blocks[9 - i].norm1_b + db.part_c[0], n_skip,
                                                 b.cout, db.gs1};
             }
+            g.splitk_scratch = sk; g.splitk_scratch_bytes = (long long)n->sk_bytes;
             TRY(gemm_dispatch(g, st));
         }
         outs[i] = Act{raw, n_next, n_skip, b.cout};
@@ -429,6 +440,7 @@ int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t
         } else {
             g.out_f32 = eps; g.ldo_f32 = lde;
         }
+        g.splitk_scratch = sk; g.splitk_scratch_bytes = (long long)n->sk_bytes;
         TRY(gemm_dispatch(g, st));
     }
     return ADCDIFF_OK;

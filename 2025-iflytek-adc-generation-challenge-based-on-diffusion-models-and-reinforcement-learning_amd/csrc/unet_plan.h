@@ -103,6 +103,8 @@ struct adcdiff_unet {
     float *sin_table, *te_pre, *te_hidden, *te_table, *s_table, *wtp_all, *btp_all, *tb_table;
     float *s_cond, *tb_cond;   // the sampling loops' table for a one-row condition: SiLU(t_emb + c_emb) and every block's time_proj of it, per timestep
     void *w_out, *w_c0, *w_c2;
+    void* sk_scratch;          // split-K scratch of the few-row GEMMs: 4096 bytes of arrival counters, then partial sums
+    size_t sk_bytes;
     size_t arena_used;
     bool packed;
     adcdiff::PackItem* pack_table;      // device copy of the packing entries (in the arena), n_pack entries, pack_chunks chunks

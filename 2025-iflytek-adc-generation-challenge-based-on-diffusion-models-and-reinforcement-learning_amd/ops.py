@@ -51,8 +51,11 @@ def _operand(x, code):
 
 
 def _raw_gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=None, act=0, out_f32=True, out_op=False, gn=(),
-         m_valid=None, dtype="fp32", eps=1e-5, tile_hint=0, split_k=0, update=None):
+         m_valid=None, dtype="fp32", eps=1e-5, tile_hint=0, split_k=0, update=None, splitk_scratch=None):
     """adcdiff_gemm: v = [A0|A1|A2] @ w.T + bias + rowbias + residual.
+
+    splitk_scratch: a uint8 device tensor whose first 4096 bytes are zero (adcdiff_gemm_args.splitk_scratch): lets a bf16 launch
+    with at most 64 live rows split K over workgroups.
 
     a_list: operand tensors [M, K_s] (M a multiple of 128) already in the operand dtype; w [N, sum K_s]; residual in the
     operand dtype; gn: up to two (gamma, beta, group_size) for fused SiLU(GroupNorm(v)) outputs in the operand dtype.
@@ -83,6 +86,8 @@ def _raw_gemm(a_list, w, bias=None, rowbias=None, rowbias_idx=None, residual=Non
         args.residual, args.ldr = residual.data_ptr(), residual.stride(0)
     args.act = act
     args.tile_hint = tile_hint
+    if splitk_scratch is not None:
+        args.splitk_scratch, args.splitk_scratch_bytes = splitk_scratch.data_ptr(), splitk_scratch.numel()
     if tile_hint:   # forcing a kernel is a test / measurement request: the library honours hints only behind its debug gate
         _lib.debug_set("tile_hints", 1)
     outs = []

@@ -121,6 +121,13 @@ typedef struct adcdiff_gemm_args {
                                   out_f32 as the sole output and no bias / rowbias / residual / act. */
     long long split_stride;    /* floats between consecutive partial outputs */
     adcdiff_step_update update;/* kind 0 = none; see adcdiff_step_update */
+    void* splitk_scratch;      /* optional device buffer (16-byte aligned) that lets a bf16 launch with at most 64 live rows split K over
+                                  workgroups inside the library: the first 4096 bytes are arrival counters that must be ZERO before the
+                                  first launch that uses the buffer (every launch leaves them zero), the rest holds partial sums,
+                                  4 * S * 64 * N bytes for S <= 16 splits (4096 + 4 MiB covers N <= 1024, 8 MiB N <= 2048).  Launches that
+                                  share the buffer must be ordered by one stream.  The result then equals the other kernels' up to float32
+                                  summation order (S partial sums added in a fixed order), not bit for bit.  NULL = never split. */
+    long long splitk_scratch_bytes;
 } adcdiff_gemm_args;
 int adcdiff_gemm(const adcdiff_gemm_args* args, adcdiff_stream_t stream);
 
@@ -344,14 +351,15 @@ int adcdiff_clip_adamw_step_noalloc(const adcdiff_opt_tensor* tensors, int n_ten
  *                        the eight-wave 256 x 256 kernel, 2560 / 2561 its phased / ring main loop, 2564 the four-wave 256 x 256
  *                        kernel with the assembly main loop, 2565 / 2566 / 2568 the same with epilogue batches of 1 / 2 / 8
  *                        rows); 1 / 3 the 128-row kernel with one LDS stage / the three-stage ring; 32 the one-wave kernel,
- *                        325 its variant with loader waves
+ *                        325 its variant with loader waves, 327 the split-K variant (needs splitk_scratch)
  *   gemm_tile (0)        128 / 256 / 2561: as the hint of that value, for every bf16 launch
  *   gemm_ring (0), gemm_ring2 (1), gemm_ring_max (512), gemm_w4 (1), gemm_w1 (1), gemm_w1_rows (1024), gemm_cl (1)
  *                        kernel-family switches of adcdiff_gemm's dispatch
+ *   gemm_splitk (1)      0 = never the few-row kernel that splits K over workgroups (splitk_scratch is ignored): small batches are
+ *                        then bit-identical to large ones
  *   step_fold (1)        0 = the reverse step and encoder.0's GroupNorm as launches of their own in the sampling loops
  *   train_transpose (0)  1 = backward products on transposed copies instead of adcdiff_gemm_tr
  *   sync (0)             1 = synchronise after every launch of adcdiff_unet_backward and name the first that fails
- *   raster (0)           workgroup -> tile order of the four-wave kernel (A/B of L2 residency)
  * Values are process-wide and read by every later call; unknown keys are rejected. */
 int adcdiff_debug_set(const char* key, long long value);
 int adcdiff_debug_get(const char* key, long long* value);

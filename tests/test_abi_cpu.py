@@ -204,7 +204,7 @@ def test_debug_switches_are_host_side_and_default_to_the_shipped_behaviour():
     reads no environment variable (its sources do not call getenv)."""
     import glob
     lib = _lib.load()
-    for key, default in (("tile_hints", 0), ("gemm_w4", 1), ("gemm_ring_max", 512), ("step_fold", 1), ("train_transpose", 0), ("raster", 0)):
+    for key, default in (("tile_hints", 0), ("gemm_w4", 1), ("gemm_ring_max", 512), ("step_fold", 1), ("train_transpose", 0), ("gemm_splitk", 1)):
         assert _lib.debug_get(key) == default, key
     _lib.debug_set("gemm_ring_max", 7)
     assert _lib.debug_get("gemm_ring_max") == 7
