@@ -393,6 +393,7 @@ const DebugEntry kDebug[DBG_NKEYS] = {
     {"gemm_splitk", 1},       // 0: never the few-row kernel that splits K over workgroups (results then bit-identical to the tile kernels)
     {"step_fold", 1},         // 0: the reverse step as a launch of its own instead of the output GEMM's epilogue
     {"train_transpose", 0},   // 1: backward products on transposed copies (the NT kernel) instead of gemm_tr
+    {"train_group_dw", 1},    // 0: every weight-gradient product of the backward pass as a launch of its own
     {"sync", 0},              // 1: synchronise and check after every training launch
 };
 std::atomic<long long> g_debug[DBG_NKEYS];

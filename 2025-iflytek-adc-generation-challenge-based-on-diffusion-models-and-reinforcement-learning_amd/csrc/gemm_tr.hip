@@ -20,7 +20,7 @@
 // slice writing its own partial output (summed by the caller in slice order).
 #include <cstdlib>
 
-#include "common.h"
+#include "unet_plan.h"
 
 namespace adcdiff {
 
@@ -59,19 +59,17 @@ __device__ __forceinline__ bf16x8 tr_fragment(const char* tile, int k0, int c0, 
 
 // NSTAGE = 3: one workgroup per CU with two tiles in flight; NSTAGE = 2 (64 KiB): two workgroups share a CU and one computes
 // while the other waits at its barrier -- for launches with more workgroups than CUs.
+// one 128 x 128 tile: workgroup `bid` of the `nwg` of its problem, contraction slice `slice`
 template <bool TA, int NSTAGE>
-__global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void gemm_tr_kernel(const TrParams p) {
+__device__ __forceinline__ void tr_tile(const TrParams& p, int bid, int nwg, int slice, char* smem) {
     constexpr int STAGE_BYTES = 32768, A_BYTES = 16384, AHEAD = NSTAGE - 1, P = 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    int bid = blockIdx.x;
-    const int nwg = gridDim.x;
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int m0 = (bid / p.ntn) * 128, n0 = (bid % p.ntn) * 128;
-    const bf16_t* const A = p.A + (long)blockIdx.y * p.a_slice;
-    const bf16_t* const B = p.B + (long)blockIdx.y * p.b_slice;
+    const bf16_t* const A = p.A + (long)slice * p.a_slice;
+    const bf16_t* const B = p.B + (long)slice * p.b_slice;
 
     // staging: this wave's four 1 KiB pieces of each operand tile
     const char* a_src[4];
@@ -147,7 +145,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void gemm_tr_kernel(const
     }
 
     // C/D layout of the 16x16 tile: col = l & 15, row = 4 * (l >> 4) + r
-    float* const C = p.C + (long)blockIdx.y * p.c_slice;
+    float* const C = p.C + (long)slice * p.c_slice;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -161,6 +159,32 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void gemm_tr_kernel(const
 }
 
 template <bool TA, int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void gemm_tr_kernel(const TrParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tr_tile<TA, NSTAGE>(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, smem);
+}
+
+// Several d(W) = d(y)^T x products in ONE launch: the weight gradients of a backward pass feed nothing but the optimizer, so
+// they can all wait for its end, where one launch with thousands of tiles fills the chip (a product on its own has 4 to 256
+// tiles and a fixed cost per launch).  Workgroup -> problem by binary search in the prefix table of tile counts.
+struct TrGroup {
+    const TrParams* probs;
+    const int* first_tile;   // nprob + 1 entries
+    int nprob;
+};
+__global__ __launch_bounds__(256, 2) void gemm_tr_grouped_kernel(const TrGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = (int)blockIdx.x;
+    int lo = 0, hi = g.nprob - 1;
+    while (lo < hi) {   // last problem whose first tile <= b (workgroup-uniform)
+        const int mid = (lo + hi + 1) >> 1;
+        if (g.first_tile[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    const TrParams p = g.probs[lo];
+    tr_tile<true, 2>(p, b - g.first_tile[lo], 1, 0, smem);
+}
+
+template <bool TA, int NSTAGE>
 static int launch_tr(const TrParams& p, dim3 grid, hipStream_t stream) {
     constexpr int smem = NSTAGE * 32768;
     // once per process, thread-safe (initialisation of a function-local static)
@@ -170,16 +194,14 @@ static int launch_tr(const TrParams& p, dim3 grid, hipStream_t stream) {
     return ADCDIFF_OK;
 }
 
-// C[M, N] (+ slices) = A * B over K.  ta: A is [K, M] row-major (lda >= M), else [M, K] row-major (lda >= K); B is [K, N]
-// row-major.  slices > 1: slice s takes K / slices contraction rows and writes C + s * c_slice.
-int gemm_tr(bool ta, const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, int slices, long c_slice,
-            hipStream_t stream) {
+static int tr_params(bool ta, const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, int slices, long c_slice,
+                     TrParams* out) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || M % 128 || N % 128 || slices < 1 || K % (64 * slices) != 0)
         return fail(ADCDIFF_E_BADARG, "gemm_tr: M=%d N=%d must be multiples of 128, K=%d of 64 x slices (%d)", M, N, K, slices);
     if (!aligned16(A) || !aligned16(B) || !aligned16(C) || lda % 8 || ldb % 8 || ldb < N || lda < (ta ? M : K) || ldc < N)
         return fail(ADCDIFF_E_BADARG, "gemm_tr: operands must be 16-byte aligned with leading dimensions that are multiples of 8 and cover the rows");
     if (slices > 1 && c_slice < (long)(M - 1) * ldc + N) return fail(ADCDIFF_E_BADARG, "gemm_tr: c_slice=%ld does not hold one output", c_slice);
-    TrParams p;
+    TrParams& p = *out;
     p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda;
     p.B = reinterpret_cast<const bf16_t*>(B); p.ldb = ldb;
     p.C = C; p.ldc = ldc;
@@ -189,6 +211,61 @@ int gemm_tr(bool ta, const void* A, long lda, const void* B, long ldb, float* C,
     p.a_slice = ta ? (long)kslice * lda : (long)kslice;
     p.b_slice = (long)kslice * ldb;
     p.c_slice = slices > 1 ? c_slice : 0;
+    return ADCDIFF_OK;
+}
+
+// The queued products C_i[M_i, N_i] = A_i^T B_i (A_i [K, M_i], B_i [K, N_i] row-major, K_i contraction rows) in one launch.  `table`
+// is device memory of gemm_tr_table_bytes(n) bytes that must stay untouched until the launch has run; the host copy of the
+// problem list is staged by the runtime before this returns (stream-ordered copy from pageable memory).
+size_t gemm_tr_table_bytes(int nprob) { return (size_t)nprob * sizeof(TrParams) + (size_t)(nprob + 1) * sizeof(int) + 64; }
+
+int gemm_tr_grouped(const TrProblem* probs, int nprob, void* table, hipStream_t stream) {
+    if (nprob <= 0) return ADCDIFF_OK;
+    if (nprob > TR_MAX_GROUP || !table || !aligned16(table)) return fail(ADCDIFF_E_BADARG, "gemm_tr_grouped: %d problems (at most %d), table %p", nprob, TR_MAX_GROUP, table);
+    struct Host { TrParams p[TR_MAX_GROUP]; int first[TR_MAX_GROUP + 1]; };
+    static thread_local Host h;
+    // the largest products first: the tail of the launch is then made of small tiles
+    int order[TR_MAX_GROUP];
+    for (int i = 0; i < nprob; ++i) order[i] = i;
+    for (int i = 1; i < nprob; ++i)
+        for (int j = i; j > 0 && (double)probs[order[j]].M * probs[order[j]].N * probs[order[j]].K > (double)probs[order[j - 1]].M * probs[order[j - 1]].N * probs[order[j - 1]].K; --j) {
+            const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+        }
+    int tiles = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < nprob; ++i) {
+        const TrProblem& q = probs[order[i]];
+        const int rc = tr_params(true, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, 1, 0, &h.p[i]);
+        if (rc != ADCDIFF_OK) return rc;
+        h.first[i] = tiles;
+        tiles += (q.M / 128) * (q.N / 128);
+        flops += 2.0 * q.M * q.N * q.K;
+        bytes += 2.0 * ((double)q.M * q.K + (double)q.N * q.K) + 4.0 * q.M * q.N;
+    }
+    h.first[nprob] = tiles;
+    char* const dev = reinterpret_cast<char*>(table);
+    const size_t pbytes = (size_t)nprob * sizeof(TrParams);
+    if (hipMemcpyAsync(dev, h.p, pbytes, hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(dev + (pbytes + 15) / 16 * 16, h.first, (size_t)(nprob + 1) * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess)
+        return fail(ADCDIFF_E_LAUNCH, "gemm_tr_grouped: copying the problem table failed");
+    constexpr int smem = 2 * 32768;
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tr_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm_tr: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    TrGroup g{reinterpret_cast<const TrParams*>(dev), reinterpret_cast<const int*>(dev + (pbytes + 15) / 16 * 16), nprob};
+    TimingScope ts(ADCDIFF_KIND_GEMM_BF16, tiles * 128, 128, 0, flops, bytes, stream);
+    hipLaunchKernelGGL(gemm_tr_grouped_kernel, dim3((unsigned)tiles), dim3(256), smem, stream, g);
+    return check_launch("gemm_tr_grouped");
+}
+
+// C[M, N] (+ slices) = A * B over K.  ta: A is [K, M] row-major (lda >= M), else [M, K] row-major (lda >= K); B is [K, N]
+// row-major.  slices > 1: slice s takes K / slices contraction rows and writes C + s * c_slice.
+int gemm_tr(bool ta, const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, int slices, long c_slice,
+            hipStream_t stream) {
+    TrParams p;
+    {
+        const int rc0 = tr_params(ta, A, lda, B, ldb, C, ldc, M, N, K, slices, c_slice, &p);
+        if (rc0 != ADCDIFF_OK) return rc0;
+    }
     const dim3 grid((unsigned)((M / 128) * p.ntn), (unsigned)slices);
     TimingScope ts(ADCDIFF_KIND_GEMM_BF16, M, N, K, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N * slices, stream);
     const bool two_ok = debug_value(DBG_GEMM_RING2) != 0;

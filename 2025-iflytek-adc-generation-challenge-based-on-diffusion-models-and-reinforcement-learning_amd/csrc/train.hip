@@ -366,8 +366,21 @@ static int gemm_dw(int dt, const void* A, const void* W, int M, int N, int K, fl
 
 // d(weight)[M, N] (rows ldo apart) = dY[K, M]^T X[K, N] on the operands as the forward pass stored them (K = batch rows), the
 // contraction cut into slices when M x N alone leaves most CUs idle; partials are summed in slice order.
+struct DwQueue {
+    TrProblem probs[TR_MAX_GROUP];
+    int n = 0;
+};
+
+// queue: the product is recorded and runs later, with all the others of the backward pass, as one launch (gemm_tr_grouped) -- its
+// operands and its output must stay untouched until then; without a queue it is launched now
 static int gemm_dw_direct(const void* dY, long ldy, const void* X, long ldx, int M, int N, int K, float* out, long ldo, int n_whole, Bump& ws,
-                          bool dry, hipStream_t st) {
+                          bool dry, hipStream_t st, DwQueue* queue = nullptr) {
+    if (queue) {
+        if (dry) return ADCDIFF_OK;
+        if (queue->n >= TR_MAX_GROUP) return fail(ADCDIFF_E_BADARG, "unet_backward: weight-gradient queue overflow");
+        queue->probs[queue->n++] = TrProblem{dY, ldy, X, ldx, out, ldo, M, N, K};
+        return ADCDIFF_OK;
+    }
     // the slicing of the transposing path (which takes a concatenated input in one product of n_whole columns): same bits
     const int slices = dw_slices(M, n_whole, K);
     if (slices == 1) {
@@ -544,10 +557,22 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
     // they are (gemm_tr); otherwise the NT kernel on transposed copies
     const bool direct = dt == ADCDIFF_BF16 && B % 64 == 0 && direct_enabled();
     if (cond && !direct) RUN(transpose_op(tp.s_op, H, B, Bp, H, dt, sT, st));
+    // The weight gradients of the blocks and of the output layer feed nothing in this pass: they are queued and run as ONE launch
+    // behind the last block (thousands of tiles instead of 4 to 256 per product, no split over the batch, no partial sums).
+    // Their d(y) operands therefore get buffers of their own per block, alive to the end.
+    DwQueue dwq;
+    DwQueue* const q_dw = direct && debug_value(DBG_TRAIN_GROUP_DW) != 0 ? &dwq : nullptr;
+    void* dY_keep[10][2] = {};
+    void* dw_table = nullptr;
+    if (direct) {
+        for (int i = 0; i < 10; ++i)
+            for (int k = 0; k < 2; ++k) dY_keep[i][k] = ws.take((size_t)Bp * n->blk[i].cout * e);
+        dw_table = ws.take(gemm_tr_table_bytes(TR_MAX_GROUP));
+    }
     if (direct) {
         void* dE_rm = ws.take((size_t)Bp * O * e);
         RUN(cast_rows(d_eps, lde, B, Bp, O, dE_rm, O, gr->out_b, nullptr, st));
-        TRY(gemm_dw_direct(dE_rm, O, tp.a_out, H, O, H, B, gr->out_w, H, H, ws, dry, st));
+        TRY(gemm_dw_direct(dE_rm, O, tp.a_out, H, O, H, B, gr->out_w, H, H, ws, dry, st, q_dw));
         float* d_a = (float*)ws.take((size_t)Bp * H * 4);
         RUN(gemm_tr(false, dE_rm, O, n->w_out, H, d_a, H, Bp, H, O, 1, 0, st));
         TRY(gn_silu_bwd(tp.blk[9].o, n->blk[9].cout, d_a, H, B, H, num_groups(H), p.out_norm_w, p.out_norm_b, 0.0f, 0, 0, 0, nullptr, 0, dO[9],
@@ -582,14 +607,14 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         long ld_raw = cin, ld_a1 = cin;
         if (direct) {
             // (1) dO in bf16; its column sums are d(linear2.bias) (= d(residual_proj.bias))
-            void* dY = ws.take((size_t)Bp * cout * e);
+            void* dY = dY_keep[i][0];
             RUN(cast_rows(dO[i], cout, B, Bp, cout, dY, cout, g.linear2_b, b.has_res ? g.residual_b : nullptr, st));
             // (2) d(linear2.weight) = dO^T a2; (3) d(residual_proj.weight) = dO^T x, part by part
-            TRY(gemm_dw_direct(dY, cout, bt.a2, cout, cout, cout, B, g.linear2_w, cout, cout, ws, dry, st));
+            TRY(gemm_dw_direct(dY, cout, bt.a2, cout, cout, cout, B, g.linear2_w, cout, cout, ws, dry, st, q_dw));
             if (b.has_res) {
                 int col0 = 0;
                 for (int k = 0; k < b.nparts; ++k) {
-                    TRY(gemm_dw_direct(dY, cout, bt.in_raw[k], b.part_c[k], cout, b.part_c[k], B, g.residual_w + col0, cin, cin, ws, dry, st));
+                    TRY(gemm_dw_direct(dY, cout, bt.in_raw[k], b.part_c[k], cout, b.part_c[k], B, g.residual_w + col0, cin, cin, ws, dry, st, q_dw));
                     col0 += b.part_c[k];
                 }
             }
@@ -603,6 +628,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             TRY(gn_silu_bwd(bt.h1, cout, d_both, n2, B, cout, b.g2, q.norm2_w, q.norm2_b, tp.drop_p, tp.drop_seed, (uint32_t)i, 0, nullptr, 0, d_h1,
                             cout, 0, g.norm2_w, g.norm2_b, ws, dry, st));
             // (6) d(h1) in bf16: column sums are d(linear1.bias) = d(time_proj.bias); (7) rows go to the timestep table
+            dY = dY_keep[i][1];
             RUN(cast_rows(d_h1, cout, B, Bp, cout, dY, cout, g.linear1_b, g.time_proj_b, st));
             if (!cond) {
                 const long total = (long)B * cout;
@@ -614,9 +640,9 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
                 }
             }
             // (8) d(linear1.weight) = d_h1^T a1; (9) d(a1) = d_h1 W1 (the first cin columns of the packed [W1 | Wtp])
-            TRY(gemm_dw_direct(dY, cout, bt.a1, cin, cout, cin, B, g.linear1_w, cin, cin, ws, dry, st));
+            TRY(gemm_dw_direct(dY, cout, bt.a1, cin, cout, cin, B, g.linear1_w, cin, cin, ws, dry, st, q_dw));
             // with a condition also d(time_proj.weight) = d_h1^T s, and [d(a1) | d(s)] = d_h1 [W1 | Wtp] in one product
-            if (cond || dry) TRY(gemm_dw_direct(dY, cout, tp.s_op, H, cout, H, B, g.time_proj_w, H, H, ws, dry, st));
+            if (cond || dry) TRY(gemm_dw_direct(dY, cout, tp.s_op, H, cout, H, B, g.time_proj_w, H, H, ws, dry, st, q_dw));
             ld_a1 = cond ? cin + H : cin;
             d_a1 = (float*)ws.take((size_t)Bp * (cin + H) * 4);
             RUN(gemm_tr(false, dY, cout, b.w1cat, b.ldw1, d_a1, ld_a1, Bp, (int)ld_a1, cout, 1, 0, st));
@@ -697,6 +723,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             col += b.part_c[k];
         }
     }
+    if (q_dw && !dry) TRY(gemm_tr_grouped(dwq.probs, dwq.n, dw_table, st));
     // ---- time branch: tb_table = SiLU(te_table) Wtp_all^T + btp_all; te_table = te_hidden W2^T + b2; te_hidden = SiLU(te_pre);
     //      te_pre = sinusoid W1^T + b1 (all float32, M = Tp rows of which only the drawn timesteps carry gradient)
     ws.off = mark;

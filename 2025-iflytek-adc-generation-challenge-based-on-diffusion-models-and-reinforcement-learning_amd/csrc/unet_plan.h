@@ -11,6 +11,16 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream);
 // gemm_tr.hip: bf16 product on contraction-major operands (see adcdiff_gemm_tr)
 int gemm_tr(bool ta, const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, int slices, long c_slice,
             hipStream_t stream);
+// gemm_tr.hip: queued transposed-A products C = A^T B run as one launch (the weight gradients of a backward pass)
+struct TrProblem {
+    const void* A; long lda;    // [K, M] row-major bf16
+    const void* B; long ldb;    // [K, N] row-major bf16
+    float* C; long ldc;         // [M, N] float32
+    int M, N, K;
+};
+constexpr int TR_MAX_GROUP = 64;
+size_t gemm_tr_table_bytes(int nprob);
+int gemm_tr_grouped(const TrProblem* probs, int nprob, void* table, hipStream_t stream);
 int groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const float* gamma, const float* beta, float eps,
                    int out_dtype, void* out, int ldo, void* raw_out, int ldraw, hipStream_t stream, float drop_p = 0.0f,
                    uint64_t drop_seed = 0, uint32_t drop_layer = 0);

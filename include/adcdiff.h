@@ -359,6 +359,8 @@ int adcdiff_clip_adamw_step_noalloc(const adcdiff_opt_tensor* tensors, int n_ten
  *                        then bit-identical to large ones
  *   step_fold (1)        0 = the reverse step and encoder.0's GroupNorm as launches of their own in the sampling loops
  *   train_transpose (0)  1 = backward products on transposed copies instead of adcdiff_gemm_tr
+ *   train_group_dw (1)   0 = every weight-gradient product of adcdiff_unet_backward as a launch of its own (split over the batch,
+ *                        partial sums) instead of one grouped launch at the end of the pass
  *   sync (0)             1 = synchronise after every launch of adcdiff_unet_backward and name the first that fails
  * Values are process-wide and read by every later call; unknown keys are rejected. */
 int adcdiff_debug_set(const char* key, long long value);

@@ -168,8 +168,9 @@ def test_backward_without_transposed_copies_gives_the_same_gradients(dims, B, co
     t = torch.randint(0, 1000, (B,), generator=gen).cuda()
     cond = torch.randn(B, dims[0], generator=gen).cuda() if conditional else None
 
-    def grads(transpose):
+    def grads(transpose, grouped=False):
         adcdiff._lib.debug_set("train_transpose", 1 if transpose else 0)
+        adcdiff._lib.debug_set("train_group_dw", 1 if grouped else 0)
         m.model.zero_grad(set_to_none=True)
         torch.manual_seed(3)             # the dropout seed is drawn from torch: same masks in both passes
         loss = m.p_losses(x, t, cond, noise=nz)
@@ -178,9 +179,15 @@ def test_backward_without_transposed_copies_gives_the_same_gradients(dims, B, co
         return {k: p.grad.clone() for k, p in m.model.named_parameters() if p.grad is not None}
 
     try:
-        direct, copies = grads(False), grads(True)
+        direct, copies, grouped = grads(False), grads(True), grads(False, grouped=True)
     finally:
         adcdiff._lib.debug_set("train_transpose", 0)
+        adcdiff._lib.debug_set("train_group_dw", 1)
+    # the shipped form: all weight-gradient products of the pass in one launch, none of them split over the batch -- the same
+    # numbers up to the float32 order in which the batch slices were added
+    assert grouped.keys() == direct.keys()
+    for k in direct:
+        assert float((grouped[k] - direct[k]).abs().max()) <= 2e-5 * max(float(direct[k].abs().max()), 1e-6) + (2e-2 * float(direct[k].abs().max()) if "time" in k else 0.0), k
     assert len(direct) >= 100 and direct.keys() == copies.keys()
     exact = 0
     for k in direct:
