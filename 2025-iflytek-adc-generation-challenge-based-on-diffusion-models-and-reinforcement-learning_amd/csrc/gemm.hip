@@ -59,6 +59,7 @@ struct GemmParams {
     int ksplit;                  // grid.y: K slices (1 without split-K)
     long long split_k_bytes;     // byte offset along K of slice blockIdx.y (0 without split-K)
     long long split_out_stride;  // floats between the partial outputs of consecutive slices
+    int pf_w;                    // four-wave kernel: prefetch the W rows as well (measurement switch)
     int sk_splits;               // few-row split-K kernel: workgroups per output tile (0 = not used)
     float* sk_part;              // its partial accumulators, [tiles][sk_splits][TM * TN][64 lanes][4] floats
     unsigned* sk_cnt;            // its arrival counters, one per output tile; zero before and after every launch
@@ -1271,6 +1272,12 @@ __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams 
         v_src1[s] = (int)((unsigned)(lane >> 3) * ld + (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) * 16));
         v_pf[s] = pf_wave ? (int)((unsigned)pf_row * ld + (unsigned)pf_k) : 0;
     }
+    // The W rows of a column tile are fetched by the four row tiles that an XCD runs side by side: the W loaders' prefetch load
+    // (otherwise a single line) touches this workgroup's quarter of them, 64 rows of one K tile
+    if (p.pf_w && !loads_a) {
+        const int wrow0 = ((bid / p.ntn) & 3) * 64;
+        if ((wrow0 >> 7) == half) v_pf[0] = (int)((unsigned)((wrow0 & 127) + lane) * (unsigned)seg_ld[0]);
+    }
 
     f32x4 acc[TM][TN];
     asm volatile(ADCDIFF_W4_MAINLOOP_ASM
@@ -1341,6 +1348,7 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
     if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmParams q = p;
     q.ntn = p.N / 256;
+    q.pf_w = (int)debug_value(DBG_GEMM_PF_W);
     const int grid = (p.M / 256) * q.ntn;
     hipLaunchKernelGGL(gemm256w_bf16_kernel<EPI_U>, dim3(grid), dim3(256), smem, stream, q);
     return check_launch("gemm256w");

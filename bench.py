@@ -337,6 +337,7 @@ def main():
     ap.add_argument("--timesteps", type=int, default=1000, help="reverse steps per pass (1000 = the metric's T)")
     ap.add_argument("--condition", action="store_true", help="conditional sampling: a one-row condition repeated to the batch")
     ap.add_argument("--sampler", choices=["ddpm", "ddim50"], default="ddpm")
+    ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE", help="a measurement switch of the library (adcdiff_debug_set), for A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="default workload only: skip the float32 batch-4096 (configs[1]) side result")
     args = ap.parse_args()
@@ -352,6 +353,8 @@ def main():
     if args.workload == "launcher_selftest":
         return launcher_selftest(args, rank, world)
     load_runtime()
+    for kv in args.debug:
+        _lib.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
