@@ -63,13 +63,14 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                           float drop_p, uint64_t drop_seed, uint32_t drop_layer, int drop_col0,
                                                           const float* __restrict__ add, long ldadd, float* __restrict__ dst, long lddst,
-                                                          int accumulate, float* __restrict__ part, long part_stride) {
-    __shared__ float red[2][4 * 256];
+                                                          int accumulate, float* __restrict__ part, long part_stride,
+                                                          bf16_t* __restrict__ dst_op, long lddo, int want_colsum) {
+    __shared__ float red[3][4 * 256];
     const int cq = threadIdx.x % c4t, ry = threadIdx.x / c4t, ryc = 256 / c4t;
     const int col = (blockIdx.x * c4t + cq) * 4;
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
     const f32x4 b = *reinterpret_cast<const f32x4*>(beta + col);
-    f32x4 dg = {0, 0, 0, 0}, db = {0, 0, 0, 0};
+    f32x4 dg = {0, 0, 0, 0}, db = {0, 0, 0, 0}, cs = {0, 0, 0, 0};
     const int rbeg = (blockIdx.y * ryc + ry) * rpt;
     const int rend = rbeg + rpt < rows ? rbeg + rpt : rows;
     for (int r0 = rbeg; r0 < rend; r0 += 2) {
@@ -127,6 +128,16 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* __restric
                     for (int i = 0; i < 4; ++i) o[i] += a[i];
                 }
                 *reinterpret_cast<f32x4*>(dp) = o;
+                // the finished value also in bf16 (the operand of the two backward products it enters) and into its column sums
+                // (the gradient of the bias of the layer that produced u's tensor)
+                if (dst_op) {
+                    bf16x4 ob;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ob[i] = (bf16_t)o[i];
+                    *reinterpret_cast<bf16x4*>(dst_op + (long)r * lddo + col) = ob;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cs[i] += o[i];
             }
         }
     }
@@ -134,44 +145,68 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* __restric
     // sums over the partial rows are taken by colsum_partials_kernel -- no atomics (thousands of float atomics on the few
     // cache lines of a [C] vector serialise in L2 and cost more than the rest of this kernel)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { red[0][(ry * c4t + cq) * 4 + i] = dg[i]; red[1][(ry * c4t + cq) * 4 + i] = db[i]; }
+    for (int i = 0; i < 4; ++i) { red[0][(ry * c4t + cq) * 4 + i] = dg[i]; red[1][(ry * c4t + cq) * 4 + i] = db[i]; red[2][(ry * c4t + cq) * 4 + i] = cs[i]; }
     __syncthreads();
     if (ry == 0) {
-        f32x4 sg = {0, 0, 0, 0}, sb = {0, 0, 0, 0};
+        f32x4 sg = {0, 0, 0, 0}, sb = {0, 0, 0, 0}, sc = {0, 0, 0, 0};
         for (int y = 0; y < ryc; ++y)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { sg[i] += red[0][(y * c4t + cq) * 4 + i]; sb[i] += red[1][(y * c4t + cq) * 4 + i]; }
-        float* pr = part + (long)blockIdx.y * part_stride + col;
+            for (int i = 0; i < 4; ++i) {
+                sg[i] += red[0][(y * c4t + cq) * 4 + i]; sb[i] += red[1][(y * c4t + cq) * 4 + i]; sc[i] += red[2][(y * c4t + cq) * 4 + i];
+            }
+        float* pr = part + (long)blockIdx.y * part_stride + col;   // a partial row = (d gamma | d beta | column sums), a third of the stride each
         *reinterpret_cast<f32x4*>(pr) = sg;
-        *reinterpret_cast<f32x4*>(pr + part_stride / 2) = sb;
+        *reinterpret_cast<f32x4*>(pr + part_stride / 3) = sb;
+        if (want_colsum) *reinterpret_cast<f32x4*>(pr + 2 * (part_stride / 3)) = sc;
     }
 }
 
-// dst0[c] += sum_r part[r * stride + c],  dst1[c] += sum_r part[r * stride + stride / 2 + c]: 64 columns per workgroup
-// (16 lanes x float4), 16 row lanes that each sum every 16th row in index order, combined through LDS in lane order.
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int nrows, long stride, int C, float* __restrict__ dst0,
-                                                              float* __restrict__ dst1) {
+// The column sums over the partial rows of EVERY gn_silu_bwd launch of a backward pass, in one launch at its end (they are
+// parameter gradients: nothing in the pass reads them).  An item = one launch's partial rows; three vectors per item
+// (d gamma, d beta, the column sums), each added to up to two destinations.  A workgroup takes 64 columns of one vector of one
+// item: 16 row lanes that each sum every 16th partial row in index order, combined through LDS in lane order (deterministic).
+struct ColsumItem {
+    const float* part;
+    long stride;          // floats per partial row (3 C)
+    int nrows, C;
+    float* dst[3][2];     // null = skip
+    int first_block;      // prefix of 3 * ceil(C / 64) over the earlier items
+};
+constexpr int COLSUM_MAX_ITEMS = 32;
+
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const ColsumItem* __restrict__ items, int n_items) {
     __shared__ float red[16][64];
-    const int which = blockIdx.y;
+    int lo = 0, hi = n_items - 1;
+    const int blk = (int)blockIdx.x;
+    while (lo < hi) {   // last item whose first block <= blk (workgroup-uniform)
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const ColsumItem it = items[lo];
+    const int nb = (it.C + 63) / 64;
+    const int local = blk - it.first_block, which = local / nb, cb = local % nb;
+    float* const d0 = it.dst[which][0];
+    float* const d1 = it.dst[which][1];
+    if (!d0 && !d1) return;
     const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int c = blockIdx.x * 64 + cx * 4;
+    const int c = cb * 64 + cx * 4;
     f32x4 s = {0, 0, 0, 0};
-    if (c < C) {
-        const float* src = part + (which ? stride / 2 : 0) + c;
-        for (int r = ly; r < nrows; r += 16) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)r * stride);
+    if (c < it.C) {
+        const float* src = it.part + which * (it.stride / 3) + c;
+        for (int r = ly; r < it.nrows; r += 16) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)r * it.stride);
             s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
         }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) red[ly][cx * 4 + i] = s[i];
     __syncthreads();
-    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+    if (threadIdx.x < 64 && cb * 64 + threadIdx.x < it.C) {
         float t = 0.0f;
 #pragma unroll
         for (int y = 0; y < 16; ++y) t += red[y][threadIdx.x];
-        float* d = which ? dst1 : dst0;
-        d[blockIdx.x * 64 + threadIdx.x] += t;
+        if (d0) d0[cb * 64 + threadIdx.x] += t;
+        if (d1) d1[cb * 64 + threadIdx.x] += t;
     }
 }
 
@@ -285,9 +320,34 @@ static int transpose_op(const void* src, long lds_, int rows, int rows_pad, int 
     return cast_transpose<float>(reinterpret_cast<const float*>(src), lds_, rows, rows_pad, cols, dtype, nullptr, 0, dst_t, rows_pad, nullptr, st);
 }
 
+// geometry of a gn_silu_bwd launch: column lanes per workgroup, rows per thread, partial rows
+struct GnBwdGeom { int c4t, ryc, rpt, nby; };
+static GnBwdGeom gn_bwd_geom(int rows, int C) {
+    const int c4 = C / 4;
+    GnBwdGeom g;
+    g.c4t = c4 < 256 ? c4 : 256;
+    g.ryc = 256 / g.c4t;
+    g.rpt = 32;
+    while (g.rpt > 8 && (long)(c4 / g.c4t) * ((rows + g.ryc * g.rpt - 1) / (g.ryc * g.rpt)) < 1024) g.rpt >>= 1;
+    g.nby = (rows + g.ryc * g.rpt - 1) / (g.ryc * g.rpt);
+    while (g.nby > 512) { g.rpt <<= 1; g.nby = (rows + g.ryc * g.rpt - 1) / (g.ryc * g.rpt); }   // bounds the partial rows of a huge batch
+    return g;
+}
+static size_t gn_bwd_part_bytes(int rows, int C) { return round_up((size_t)gn_bwd_geom(rows, C).nby * 3 * C * 4, 256); }
+
+struct ColsumQueue {
+    ColsumItem items[COLSUM_MAX_ITEMS];
+    int n = 0, blocks = 0;
+    Bump parts{nullptr, 0};   // the partial rows of every launch stay until the batched column sums have run
+};
+
+// d(u) of a = dropout(SiLU(GroupNorm(u))) (see the kernel).  The partial rows of d gamma / d beta (and, with bias0, of the column
+// sums of the finished dst, which are the bias gradient of the layer that produced u: added to bias0 and bias1) go to the queue's
+// buffer and are summed by ONE launch at the end of the pass (colsum_flush).  dst_op: the finished dst in bf16 as well.
 static int gn_silu_bwd(const float* u, long ldu, const float* dA, long ldda, int rows, int C, int groups, const float* gamma,
                        const float* beta, float drop_p, uint64_t drop_seed, uint32_t drop_layer, int drop_col0, const float* add,
-                       long ldadd, float* dst, long lddst, int accumulate, float* dgamma, float* dbeta, Bump& ws, bool dry, hipStream_t st) {
+                       long ldadd, float* dst, long lddst, int accumulate, float* dgamma, float* dbeta, ColsumQueue& cq, bool dry, hipStream_t st,
+                       void* dst_op = nullptr, long lddo = 0, float* bias0 = nullptr, float* bias1 = nullptr) {
     const int gs = C / groups;
     if (gs < 4 || gs > 256 || (gs & (gs - 1)) != 0)
         return fail(ADCDIFF_E_BADARG, "training needs GroupNorm groups that are powers of two in 4..256 (got %d)", gs);
@@ -295,20 +355,32 @@ static int gn_silu_bwd(const float* u, long ldu, const float* dA, long ldda, int
     // column lanes per workgroup: all of them up to 256 (a power of two, so that it divides 256 and holds whole groups)
     if (C % 4 != 0 || (c4 <= 256 ? (c4 & (c4 - 1)) != 0 : c4 % 256 != 0))
         return fail(ADCDIFF_E_BADARG, "training needs a channel count that is a power of two up to 1024 or a multiple of 1024 (got %d)", C);
-    const int c4t = c4 < 256 ? c4 : 256, ryc = 256 / c4t;
-    int rpt = 32;
-    while (rpt > 8 && (long)(c4 / c4t) * ((rows + ryc * rpt - 1) / (ryc * rpt)) < 1024) rpt >>= 1;
-    const int nby = (rows + ryc * rpt - 1) / (ryc * rpt);
-    const size_t keep = ws.off;
-    float* part = (float*)ws.take((size_t)nby * 2 * C * 4);   // one (d gamma | d beta) row per workgroup row; dead after the column sums
-    ws.off = keep;
+    const GnBwdGeom g = gn_bwd_geom(rows, C);
     if (dry) return ADCDIFF_OK;
-    TimingScope ts(ADCDIFF_KIND_OTHER, rows, C, 0, 0.0, (double)rows * C * 12.0, st);
-    const dim3 grid((unsigned)(c4 / c4t), (unsigned)nby);
-    hipLaunchKernelGGL(gn_silu_bwd_kernel, grid, dim3(256), 0, st, u, ldu, dA, ldda, rows, c4t, rpt, gs / 4, 1.0f / (float)gs, gamma, beta, 1e-5f,
-                       drop_p, drop_seed, drop_layer, drop_col0, add, ldadd, dst, lddst, accumulate, part, (long)2 * C);
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)((C + 63) / 64), 2), dim3(256), 0, st, part, nby, (long)2 * C, C, dgamma, dbeta);
+    float* part = (float*)cq.parts.take((size_t)g.nby * 3 * C * 4);
+    if (cq.parts.off > cq.parts.cap || cq.n >= COLSUM_MAX_ITEMS) return fail(ADCDIFF_E_WORKSPACE, "unet_backward: internal sizing error (GroupNorm partial rows)");
+    TimingScope ts(ADCDIFF_KIND_OTHER, rows, C, 0, 0.0, (double)rows * C * (12.0 + (dst_op ? 2.0 : 0.0)), st);
+    const dim3 grid((unsigned)(c4 / g.c4t), (unsigned)g.nby);
+    hipLaunchKernelGGL(gn_silu_bwd_kernel, grid, dim3(256), 0, st, u, ldu, dA, ldda, rows, g.c4t, g.rpt, gs / 4, 1.0f / (float)gs, gamma, beta, 1e-5f,
+                       drop_p, drop_seed, drop_layer, drop_col0, add, ldadd, dst, lddst, accumulate, part, (long)3 * C,
+                       reinterpret_cast<bf16_t*>(dst_op), lddo, bias0 ? 1 : 0);
+    ColsumItem& it = cq.items[cq.n++];
+    it.part = part; it.stride = (long)3 * C; it.nrows = g.nby; it.C = C;
+    it.dst[0][0] = dgamma; it.dst[0][1] = nullptr; it.dst[1][0] = dbeta; it.dst[1][1] = nullptr; it.dst[2][0] = bias0; it.dst[2][1] = bias1;
+    it.first_block = cq.blocks;
+    cq.blocks += 3 * ((C + 63) / 64);
     return check_launch("gn_silu_bwd");
+}
+
+// the queued column sums in one launch; `table` is device memory for COLSUM_MAX_ITEMS items
+static int colsum_flush(ColsumQueue& cq, void* table, hipStream_t st) {
+    if (cq.n == 0) return ADCDIFF_OK;
+    if (hipMemcpyAsync(table, cq.items, (size_t)cq.n * sizeof(ColsumItem), hipMemcpyHostToDevice, st) != hipSuccess)
+        return fail(ADCDIFF_E_LAUNCH, "unet_backward: copying the column-sum table failed");
+    TimingScope ts(ADCDIFF_KIND_OTHER, cq.n, 0, 0, 0.0, (double)cq.parts.off, st);
+    hipLaunchKernelGGL(colsum_batched_kernel, dim3((unsigned)cq.blocks), dim3(256), 0, st, reinterpret_cast<const ColsumItem*>(table), cq.n);
+    cq.n = 0; cq.blocks = 0;
+    return check_launch("colsum_batched");
 }
 
 static int gemm_simple(int dt, const void* A, int lda, const void* W, int ldw, int M, int m_valid, int N, int K, float* out, int ldo,
@@ -568,7 +640,27 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         for (int i = 0; i < 10; ++i)
             for (int k = 0; k < 2; ++k) dY_keep[i][k] = ws.take((size_t)Bp * n->blk[i].cout * e);
         dw_table = ws.take(gemm_tr_table_bytes(TR_MAX_GROUP));
+        // rows B .. Bp of these operands are read by the d(x) products (M = Bp): zero, as the cast kernels left them
+        if (!dry && Bp > B)
+            for (int i = 0; i < 10; ++i)
+                for (int k = 0; k < 2; ++k)
+                    if (hipMemsetAsync((char*)dY_keep[i][k] + (size_t)B * n->blk[i].cout * e, 0, (size_t)(Bp - B) * n->blk[i].cout * e, st) != hipSuccess)
+                        return fail(ADCDIFF_E_LAUNCH, "unet_backward: memset failed");
     }
+    // every GroupNorm backward launch leaves partial rows (d gamma | d beta | column sums) that one launch sums at the end
+    ColsumQueue cq;
+    {
+        size_t need = gn_bwd_part_bytes(B, H);
+        for (int i = 0; i < 10; ++i) {
+            need += gn_bwd_part_bytes(B, n->blk[i].cout);
+            for (int k = 0; k < n->blk[i].nparts; ++k) need += gn_bwd_part_bytes(B, n->blk[i].part_c[k]);
+        }
+        cq.parts = Bump(ws.take(need), need);
+    }
+    void* const colsum_table = ws.take((size_t)COLSUM_MAX_ITEMS * sizeof(ColsumItem));
+    // direct path: the bf16 copy of a finished d(block output) / d(h1) and its column sums (bias gradients) come out of the
+    // GroupNorm backward kernel that finishes it, instead of a cast pass over it
+    const bool fuse_cast = direct && debug_value(DBG_TRAIN_FUSE_CAST) != 0;
     if (direct) {
         void* dE_rm = ws.take((size_t)Bp * O * e);
         RUN(cast_rows(d_eps, lde, B, Bp, O, dE_rm, O, gr->out_b, nullptr, st));
@@ -576,7 +668,8 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         float* d_a = (float*)ws.take((size_t)Bp * H * 4);
         RUN(gemm_tr(false, dE_rm, O, n->w_out, H, d_a, H, Bp, H, O, 1, 0, st));
         TRY(gn_silu_bwd(tp.blk[9].o, n->blk[9].cout, d_a, H, B, H, num_groups(H), p.out_norm_w, p.out_norm_b, 0.0f, 0, 0, 0, nullptr, 0, dO[9],
-                        n->blk[9].cout, 0, gr->out_norm_w, gr->out_norm_b, ws, dry, st));
+                        n->blk[9].cout, 0, gr->out_norm_w, gr->out_norm_b, cq, dry, st, fuse_cast ? dY_keep[9][0] : nullptr, n->blk[9].cout,
+                        fuse_cast ? gr->blocks[9].linear2_b : nullptr, fuse_cast && n->blk[9].has_res ? gr->blocks[9].residual_b : nullptr));
         dO_written[9] = true;
     } else {
         void* dE_rm = ws.take((size_t)Bp * O * e);
@@ -590,7 +683,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         float* d_a = (float*)ws.take((size_t)Bp * H * 4);
         RUN(gemm_simple(dt, dE_rm, O, wT, O, Bp, B, H, O, d_a, H, st));
         TRY(gn_silu_bwd(tp.blk[9].o, n->blk[9].cout, d_a, H, B, H, num_groups(H), p.out_norm_w, p.out_norm_b, 0.0f, 0, 0, 0, nullptr, 0, dO[9],
-                        n->blk[9].cout, 0, gr->out_norm_w, gr->out_norm_b, ws, dry, st));
+                        n->blk[9].cout, 0, gr->out_norm_w, gr->out_norm_b, cq, dry, st));
         dO_written[9] = true;
     }
     const size_t mark = ws.off;
@@ -608,7 +701,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         if (direct) {
             // (1) dO in bf16; its column sums are d(linear2.bias) (= d(residual_proj.bias))
             void* dY = dY_keep[i][0];
-            RUN(cast_rows(dO[i], cout, B, Bp, cout, dY, cout, g.linear2_b, b.has_res ? g.residual_b : nullptr, st));
+            if (!fuse_cast) RUN(cast_rows(dO[i], cout, B, Bp, cout, dY, cout, g.linear2_b, b.has_res ? g.residual_b : nullptr, st));
             // (2) d(linear2.weight) = dO^T a2; (3) d(residual_proj.weight) = dO^T x, part by part
             TRY(gemm_dw_direct(dY, cout, bt.a2, cout, cout, cout, B, g.linear2_w, cout, cout, ws, dry, st, q_dw));
             if (b.has_res) {
@@ -626,10 +719,11 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             // (5) through dropout, SiLU and norm2 to d(h1)
             float* d_h1 = (float*)ws.take((size_t)Bp * cout * 4);
             TRY(gn_silu_bwd(bt.h1, cout, d_both, n2, B, cout, b.g2, q.norm2_w, q.norm2_b, tp.drop_p, tp.drop_seed, (uint32_t)i, 0, nullptr, 0, d_h1,
-                            cout, 0, g.norm2_w, g.norm2_b, ws, dry, st));
+                            cout, 0, g.norm2_w, g.norm2_b, cq, dry, st, fuse_cast ? dY_keep[i][1] : nullptr, cout, fuse_cast ? g.linear1_b : nullptr,
+                            fuse_cast ? g.time_proj_b : nullptr));
             // (6) d(h1) in bf16: column sums are d(linear1.bias) = d(time_proj.bias); (7) rows go to the timestep table
             dY = dY_keep[i][1];
-            RUN(cast_rows(d_h1, cout, B, Bp, cout, dY, cout, g.linear1_b, g.time_proj_b, st));
+            if (!fuse_cast) RUN(cast_rows(d_h1, cout, B, Bp, cout, dY, cout, g.linear1_b, g.time_proj_b, st));
             if (!cond) {
                 const long total = (long)B * cout;
                 if (!dry) {
@@ -676,7 +770,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             RUN(gemm_simple(dt, dO_rm, cout, wT, cout, Bp, B, cout, cout, d_a2, cout, st));
             float* d_h1 = (float*)ws.take((size_t)Bp * cout * 4);
             TRY(gn_silu_bwd(bt.h1, cout, d_a2, cout, B, cout, b.g2, q.norm2_w, q.norm2_b, tp.drop_p, tp.drop_seed, (uint32_t)i, 0, nullptr, 0, d_h1,
-                            cout, 0, g.norm2_w, g.norm2_b, ws, dry, st));
+                            cout, 0, g.norm2_w, g.norm2_b, cq, dry, st));
             // (6) d(h1): column sums are d(linear1.bias) = d(time_proj.bias); (7) rows go to the timestep table
             RUN(cast_transpose<float>(d_h1, cout, B, Bp, cout, dt, dO_rm, cout, dO_t, Bp, g.linear1_b, st));
             RUN(copy_f32(g.linear1_b, g.time_proj_b, cout, 0, st));
@@ -717,8 +811,12 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             const int acc = src >= 0 && dO_written[src] ? 1 : 0;
             const float* add = b.has_res ? d_raw + col : dO[i];     // Identity residual passes dO straight through
             const long ldadd = b.has_res ? ld_raw : cout;
+            // part 0 of a block's input is the previous block's output, and this launch is the last to write its gradient (a skip
+            // consumer, one of the decoder blocks, ran earlier): it finishes d(output of block i - 1)
+            const bool fin = fuse_cast && k == 0 && src >= 0;
             TRY(gn_silu_bwd(bt.in_f32[k], bt.in_ld[k], d_a1 + col, ld_a1, B, b.part_c[k], b.part_c[k] / b.gs1, q.norm1_w + col, q.norm1_b + col, 0.0f,
-                            0, 0, 0, add, ldadd, dst, lddst, acc, g.norm1_w + col, g.norm1_b + col, ws, dry, st));
+                            0, 0, 0, add, ldadd, dst, lddst, acc, g.norm1_w + col, g.norm1_b + col, cq, dry, st, fin ? dY_keep[src][0] : nullptr, lddst,
+                            fin ? gr->blocks[src].linear2_b : nullptr, fin && n->blk[src].has_res ? gr->blocks[src].residual_b : nullptr));
             if (src >= 0) dO_written[src] = true;
             col += b.part_c[k];
         }
@@ -843,5 +941,6 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         RUN(cast_transpose<float>(n->sin_table, H, Tp, Tp, H, ADCDIFF_F32, nullptr, 0, sinT, Tp, nullptr, st));
         RUN(gemm_simple(ADCDIFF_F32, dPRE_t, Tp, sinT, Tp, 4 * H, 0, H, Tp, gr->time_lin1_w, H, st));
     }
+    if (!dry) TRY(colsum_flush(cq, colsum_table, st));
     return ADCDIFF_OK;
 }

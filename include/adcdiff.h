@@ -361,6 +361,8 @@ int adcdiff_clip_adamw_step_noalloc(const adcdiff_opt_tensor* tensors, int n_ten
  *   train_transpose (0)  1 = backward products on transposed copies instead of adcdiff_gemm_tr
  *   train_group_dw (1)   0 = every weight-gradient product of adcdiff_unet_backward as a launch of its own (split over the batch,
  *                        partial sums) instead of one grouped launch at the end of the pass
+ *   train_fuse_cast (1)  0 = the bf16 operand copies and bias gradients of adcdiff_unet_backward by cast launches of their own instead
+ *                        of the GroupNorm backward kernel that finishes the tensor
  *   sync (0)             1 = synchronise after every launch of adcdiff_unet_backward and name the first that fails
  * Values are process-wide and read by every later call; unknown keys are rejected. */
 int adcdiff_debug_set(const char* key, long long value);
