@@ -558,6 +558,8 @@ class DiffusionModel(nn.Module):
         self.optimizer = optimizer_class(self.model.parameters(), lr=config.get('learning_rate', 1e-4),
                                          weight_decay=config.get('weight_decay', 1e-2))
         self._fused_opt = None
+        self._loss_host = None     # pinned scalar + event: how train_step reads the loss without waiting for the whole step
+        self._loss_event = None
         if config.get('use_onecycle', False):
             self.scheduler = OneCycleLR(self.optimizer, max_lr=config.get('learning_rate', 1e-4),
                                         total_steps=config.get('total_steps', 10000))
@@ -818,6 +820,15 @@ class DiffusionModel(nn.Module):
         alias_before, self.model.alias_gradients = self.model.alias_gradients, True   # .grad = views of the persistent arena
         try:
             loss = self.p_losses(x, t, row_offset=rank * batch_size)
+            # The step returns the loss as a float.  Its value exists as soon as the forward pass has run, long before the
+            # backward pass and the optimizer have: it is copied to pinned host memory right here, behind the forward on the
+            # stream, and the step waits for THAT copy only -- not for the rest of the step, which the GPU finishes while the
+            # host prepares the next call.
+            if self._loss_host is None:
+                self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
+                self._loss_event = torch.cuda.Event()
+            self._loss_host.copy_(loss.detach(), non_blocking=True)
+            self._loss_event.record()
             loss = loss / self.gradient_accumulation_steps
             loss.backward()
         finally:
@@ -833,8 +844,9 @@ class DiffusionModel(nn.Module):
             self._fused_opt.step()     # clip_grad_norm_(max_norm=1.0) + optimizer.step() in three launches
             self.optimizer.zero_grad()
         memory_info = self._get_memory_usage()
+        self._loss_event.synchronize()
         return {
-            'loss': loss.item() * self.gradient_accumulation_steps,
+            'loss': float(self._loss_host),
             'lr': self.optimizer.param_groups[0]['lr'],
             'gpu_memory': memory_info.get('gpu_memory_used_gb', 0),
             'gpu_memory_percent': memory_info.get('gpu_memory_percent', 0),
