@@ -92,3 +92,41 @@ def test_split_k_applies_the_schedule_update():
             outs.append(flat(ops._raw_gemm([A], W, bias=bias, m_valid=live, dtype="bf16", tile_hint=h, out_op=True, gn=[(gam, bet, 16)], splitk_scratch=sc,
                                            update=dict(kind=kind, c=c, x=x.clone(), noise=None, seed=5, step=3, row_offset=40))))
         check(outs[0], outs[1], live, kind)
+
+
+def test_random_shapes_on_the_split_k_kernel():
+    """120 random launches (N, one to three K segments, GroupNorm group sizes, 1..64 live rows, every epilogue input present or not)
+    forced onto the split-K kernel: every output within the stated tolerance of the 128-row tile kernel, and the second of two
+    identical launches equal to the first bit for bit."""
+    rng = np.random.default_rng(23)
+    torch.manual_seed(23)
+    bf = torch.bfloat16
+    scratch = torch.zeros(SCRATCH_BYTES, device=DEV, dtype=torch.uint8)
+    for case in range(120):
+        N = int(rng.choice([128, 256, 512, 1024, 2048]))
+        Ks = [int(rng.choice([64, 128, 256, 512, 1024, 2048])) for _ in range(int(rng.integers(1, 4)))]
+        if sum(Ks) < 128:
+            Ks.append(128)                                   # at least two K tiles: one per split
+        gss = [g for g in (4, 8, 16, 32, 64, 128) if N % g == 0]
+        gs = [int(rng.choice(gss)) for _ in range(int(rng.integers(0, 3)))]
+        live = int(rng.integers(1, 65))
+        As = [torch.randn(128, k, device=DEV).to(bf) for k in Ks]
+        W = (torch.randn(N, sum(Ks), device=DEV) / sum(Ks) ** 0.5).to(bf)
+        kw = dict(dtype="bf16", m_valid=live)
+        if rng.random() < 0.7:
+            kw["bias"] = torch.randn(N, device=DEV)
+        if rng.random() < 0.4:
+            kw["rowbias"], kw["rowbias_idx"] = torch.randn(9, N, device=DEV), torch.randint(0, 9, (128,), device=DEV)
+        if rng.random() < 0.5:
+            kw["residual"] = torch.randn(128, N, device=DEV).to(bf)
+        if rng.random() < 0.5 or not gs:
+            kw["out_op"] = True
+        kw["gn"] = [(torch.rand(N, device=DEV) + 0.5, torch.randn(N, device=DEV), g) for g in gs]
+        what = dict(case=case, N=N, Ks=Ks, gs=gs, live=live)
+        ref = flat(ops._raw_gemm(As, W, tile_hint=128, **kw))
+        one = flat(ops._raw_gemm(As, W, tile_hint=327, splitk_scratch=scratch, **kw))
+        two = flat(ops._raw_gemm(As, W, tile_hint=327, splitk_scratch=scratch, **kw))
+        check(one, ref, live, what)
+        for a, b in zip(one, two):
+            assert torch.equal(a[:live], b[:live]), what
+    assert int(scratch[:4096].view(torch.int32).abs().sum()) == 0
