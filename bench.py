@@ -415,7 +415,7 @@ def main():
         # the job's one exchange, timed alone on every rank (max over ranks): the all-gather of the latents or the all-reduce
         # of the gradient arena; it is inside `elapsed` above as well
         if training:
-            flat = model.model.grad_arena_if_aliased()
+            flat = model.model._grad_flat[0] if model.model._grad_flat is not None else None   # the arena every .grad aliased during the steps
             fn_c = (lambda: parallel.allreduce_gradients(model.model.parameters(), flat=flat)) if flat is not None else None
             nbytes = flat.numel() * 4 if flat is not None else 0
             name = "RCCL all-reduce of the float32 gradient arena"
