@@ -26,6 +26,9 @@ def gather_rows(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     world = dist.get_world_size(group)
     if world == 1:
         return local
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo (tests, rehearsals of the rank logic on one GPU) gathers device tensors through the host; RCCL takes them as they are
+        return gather_rows(local.cpu(), total, group).to(local.device)
     d = local.shape[1]
     longest = shard_rows(total, world, 0)[1]
     if total % world == 0:

@@ -280,6 +280,8 @@ def launch_ranks(n):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "gloo" in sys.argv:
+        env.setdefault("GLOO_SOCKET_IFNAME", "lo")   # the rehearsal backend picks its interface by host name, which may not resolve
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
@@ -338,6 +340,8 @@ def main():
     ap.add_argument("--condition", action="store_true", help="conditional sampling: a one-row condition repeated to the batch")
     ap.add_argument("--sampler", choices=["ddpm", "ddim50"], default="ddpm")
     ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE", help="a measurement switch of the library (adcdiff_debug_set), for A/B runs")
+    ap.add_argument("--backend", default="nccl", help="process-group backend: nccl (= RCCL, the measurement) or gloo (rehearsal of the rank "
+                    "logic: the ranks may then share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="default workload only: skip the float32 batch-4096 (configs[1]) side result")
     args = ap.parse_args()
@@ -355,13 +359,21 @@ def main():
     load_runtime()
     for kv in args.debug:
         _lib.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
+    def mark(what):
+        if os.environ.get("BENCH_PROGRESS"):
+            print("[bench rank %d] %s" % (rank, what), file=sys.stderr, flush=True)
+    mark("process group up")
     dtype, batch, config_name = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
@@ -393,18 +405,24 @@ def main():
                 out = parallel.gather_rows(out, total)
             return out
 
+    mark("model built")
     for k in range(args.warmup):
         one_pass(-1 - k)
+    mark("warm-up done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    mark("barrier passed")
     t0 = time.perf_counter()
     for k in range(args.steps):
         out = one_pass(k)
+        mark("step %d enqueued" % k)
     torch.cuda.synchronize()
+    mark("device idle")
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    mark("timed steps done")
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -438,10 +456,12 @@ def main():
             collective = {"what": name, "ms": round(float(tc.item()), 4), "bytes_result_per_rank": nbytes,
                           "share_of_step": round(float(tc.item()) * 1e-3 / (elapsed / args.steps), 5)}
 
+    # live roofline: per-launch events over a short window of the same work.  A training step holds a collective (the gradient
+    # all-reduce), so with several ranks every rank runs the window's steps; rank 0 alone keeps the records
+    train_window = timed_window(lambda: model.train_step(x_train, 10 ** 6)) if training else None
     if rank == 0:
-        # live roofline: per-launch events over a short window of the same work
         if training:
-            recs, clean_ms, over = timed_window(lambda: model.train_step(x_train, 10 ** 6))
+            recs, clean_ms, over = train_window
             roofs = summarize_records(recs, dtype, count, TRAIN_FLOP_PER_SAMPLE, args.workload)
             samples = total * args.steps
             metric, sampler_desc = "train samples/sec (noise-prediction loss fwd+bwd + clip + AdamW)", "train_step"
@@ -473,7 +493,7 @@ def main():
                        "parallelism": ("rows sharded over %d GPU(s), RCCL all-gather of latents" % world) if not training else
                                       ("data parallel over %d GPU(s), RCCL all-reduce of the gradient arena" % world),
                        "weights": "random (counter RNG, xavier variance), no checkpoint ships"},
-            "outputs_finite": finite, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "outputs_finite": finite, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": args.backend if world > 1 else None,
         }
         if collective:
             line["collective"] = collective

@@ -1,0 +1,35 @@
+"""The multi-rank paths of bench.py on real kernels: `python bench.py --gpus 2` starts its own two ranks, which here share the
+one GPU and talk through gloo (`--backend gloo`: a rehearsal of the rank logic -- sharding by global row, the collective, the
+barrier / max-over-ranks timing, the roofline window -- not a measurement; the measured runs use RCCL, one GPU per rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(args):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-cpu-baseline"] + args, env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_sample_their_shards_and_gather():
+    d = run(["--batch", "256", "--timesteps", "5", "--steps", "1", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["outputs_finite"] is True and d["scaling"] == "weak"
+    assert d["config"]["per_gpu_batch"] == 256 and d["config"]["global_batch"] == 512
+    assert d["collective"]["bytes_result_per_rank"] == 512 * 512 * 4 and d["roofline"]["frac"] > 0
+
+
+def test_two_ranks_train_data_parallel():
+    """Every rank must run the roofline window's steps too: a training step holds the gradient all-reduce."""
+    d = run(["--workload", "train_dp", "--batch", "256", "--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["outputs_finite"] is True and d["collective"]["bytes_result_per_rank"] > 170e6
