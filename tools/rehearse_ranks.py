@@ -1,4 +1,6 @@
-"""The multi-rank paths of bench.py on real kernels: `python bench.py --gpus 2` starts its own two ranks, which here share the
+"""Run by hand on a GPU box (python -m pytest tools/rehearse_ranks.py -v -m gpu); kept out of tests/ because it starts process
+trees and depends on the box's loopback networking, which the round-end suite should not.
+The multi-rank paths of bench.py on real kernels: `python bench.py --gpus 2` starts its own two ranks, which here share the
 one GPU and talk through gloo (`--backend gloo`: a rehearsal of the rank logic -- sharding by global row, the collective, the
 barrier / max-over-ranks timing, the roofline window -- not a measurement; the measured runs use RCCL, one GPU per rank)."""
 import json
@@ -10,6 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def run(args):
