@@ -348,6 +348,9 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
+    if os.environ.get("BENCH_WATCHDOG"):   # all threads' stacks to stderr after that many seconds (a hung rehearsal says where)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=False)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
