@@ -90,9 +90,10 @@ def test_training_workspace_grows_affinely_with_batch():
     for dt in (0, 1):
         b = [lib.adcdiff_unet_train_workspace_bytes(512, 256, 512, 1000, dt, B) for B in (2048, 4096, 6144, 8192)]
         assert b[0] < b[1] < b[2] < b[3]
-        # affine up to the small batch-dependent reduction buffers (split-K partial products, GroupNorm-backward partial rows)
+        # affine up to the batch-dependent reduction buffers: the GroupNorm-backward partial rows of the whole pass stay until its
+        # batched column sums run, and their count moves in steps with the rows a thread takes (8 / 16 / 32)
         d = [b[1] - b[0], b[2] - b[1], b[3] - b[2]]
-        assert max(d) - min(d) <= 0.02 * min(d)
+        assert max(d) - min(d) <= 0.16 * min(d)
         # forward tape alone keeps >= 30 row-sized activations of width >= 256 per block pair
         assert b[1] > 4096 * 256 * 4 * 100
 
