@@ -103,7 +103,9 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* __restric
             for (int i = 0; i < 4; ++i) {
                 xh[i] = d[i] * rstd;
                 const float n = xh[i] * g[i] + b[i];
-                const float sig = 1.0f / (1.0f + expf(-n));
+                // v_exp_f32 / v_rcp_f32 (1 ulp each) instead of expf and a full division: the kernel is bound by its arithmetic,
+                // and a gradient does not need the forward pass's last bit
+                const float sig = __builtin_amdgcn_rcpf(1.0f + __expf(-n));
                 const float dn = da[i] * keep[i] * (sig * (1.0f + n * (1.0f - sig)));
                 if (count) { dg[i] += dn * xh[i]; db[i] += dn; }
                 dxh[i] = dn * g[i];
