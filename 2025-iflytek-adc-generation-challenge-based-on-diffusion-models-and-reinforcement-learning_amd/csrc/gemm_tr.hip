@@ -166,22 +166,33 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void gemm_tr_kernel(const
 
 // Several d(W) = d(y)^T x products in ONE launch: the weight gradients of a backward pass feed nothing but the optimizer, so
 // they can all wait for its end, where one launch with thousands of tiles fills the chip (a product on its own has 4 to 256
-// tiles and a fixed cost per launch).  Workgroup -> problem by binary search in the prefix table of tile counts.
+// tiles and a fixed cost per launch).  Workgroup -> problem by binary search in the prefix table of tile counts.  The table
+// travels as the kernel's argument (48 bytes per problem, 3.4 KB): no copy to the device, nothing to keep alive.
+struct TrItem {
+    const bf16_t* A;
+    const bf16_t* B;
+    float* C;
+    int lda, ldb, ldc;
+    int ntn, nt, first_tile;
+};
 struct TrGroup {
-    const TrParams* probs;
-    const int* first_tile;   // nprob + 1 entries
+    TrItem items[TR_MAX_GROUP];
     int nprob;
 };
+static_assert(sizeof(TrGroup) <= 3800, "the grouped launch's table must fit the kernel argument segment");
 __global__ __launch_bounds__(256, 2) void gemm_tr_grouped_kernel(const TrGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = (int)blockIdx.x;
     int lo = 0, hi = g.nprob - 1;
     while (lo < hi) {   // last problem whose first tile <= b (workgroup-uniform)
         const int mid = (lo + hi + 1) >> 1;
-        if (g.first_tile[mid] <= b) lo = mid; else hi = mid - 1;
+        if (g.items[mid].first_tile <= b) lo = mid; else hi = mid - 1;
     }
-    const TrParams p = g.probs[lo];
-    tr_tile<true, 2>(p, b - g.first_tile[lo], 1, 0, smem);
+    const TrItem it = g.items[lo];
+    TrParams p;
+    p.A = it.A; p.lda = it.lda; p.B = it.B; p.ldb = it.ldb; p.C = it.C; p.ldc = it.ldc;
+    p.ntn = it.ntn; p.nt = it.nt; p.a_slice = 0; p.b_slice = 0; p.c_slice = 0;
+    tr_tile<true, 2>(p, b - it.first_tile, 1, 0, smem);
 }
 
 template <bool TA, int NSTAGE>
@@ -214,16 +225,10 @@ static int tr_params(bool ta, const void* A, long lda, const void* B, long ldb, 
     return ADCDIFF_OK;
 }
 
-// The queued products C_i[M_i, N_i] = A_i^T B_i (A_i [K, M_i], B_i [K, N_i] row-major, K_i contraction rows) in one launch.  `table`
-// is device memory of gemm_tr_table_bytes(n) bytes that must stay untouched until the launch has run; the host copy of the
-// problem list is staged by the runtime before this returns (stream-ordered copy from pageable memory).
-size_t gemm_tr_table_bytes(int nprob) { return (size_t)nprob * sizeof(TrParams) + (size_t)(nprob + 1) * sizeof(int) + 64; }
-
-int gemm_tr_grouped(const TrProblem* probs, int nprob, void* table, hipStream_t stream) {
+// The queued products C_i[M_i, N_i] = A_i^T B_i (A_i [K, M_i], B_i [K, N_i] row-major, K_i contraction rows) in one launch.
+int gemm_tr_grouped(const TrProblem* probs, int nprob, hipStream_t stream) {
     if (nprob <= 0) return ADCDIFF_OK;
-    if (nprob > TR_MAX_GROUP || !table || !aligned16(table)) return fail(ADCDIFF_E_BADARG, "gemm_tr_grouped: %d problems (at most %d), table %p", nprob, TR_MAX_GROUP, table);
-    struct Host { TrParams p[TR_MAX_GROUP]; int first[TR_MAX_GROUP + 1]; };
-    static thread_local Host h;
+    if (nprob > TR_MAX_GROUP) return fail(ADCDIFF_E_BADARG, "gemm_tr_grouped: %d problems (at most %d)", nprob, TR_MAX_GROUP);
     // the largest products first: the tail of the launch is then made of small tiles
     int order[TR_MAX_GROUP];
     for (int i = 0; i < nprob; ++i) order[i] = i;
@@ -231,27 +236,24 @@ int gemm_tr_grouped(const TrProblem* probs, int nprob, void* table, hipStream_t 
         for (int j = i; j > 0 && (double)probs[order[j]].M * probs[order[j]].N * probs[order[j]].K > (double)probs[order[j - 1]].M * probs[order[j - 1]].N * probs[order[j - 1]].K; --j) {
             const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
         }
+    TrGroup g;
     int tiles = 0;
     double flops = 0.0, bytes = 0.0;
     for (int i = 0; i < nprob; ++i) {
         const TrProblem& q = probs[order[i]];
-        const int rc = tr_params(true, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, 1, 0, &h.p[i]);
+        TrParams p;
+        const int rc = tr_params(true, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, 1, 0, &p);
         if (rc != ADCDIFF_OK) return rc;
-        h.first[i] = tiles;
+        if (q.lda > 0x7fffffffL || q.ldb > 0x7fffffffL || q.ldc > 0x7fffffffL) return fail(ADCDIFF_E_BADARG, "gemm_tr_grouped: leading dimension too large");
+        g.items[i] = TrItem{p.A, p.B, p.C, (int)p.lda, (int)p.ldb, (int)p.ldc, p.ntn, p.nt, tiles};
         tiles += (q.M / 128) * (q.N / 128);
         flops += 2.0 * q.M * q.N * q.K;
         bytes += 2.0 * ((double)q.M * q.K + (double)q.N * q.K) + 4.0 * q.M * q.N;
     }
-    h.first[nprob] = tiles;
-    char* const dev = reinterpret_cast<char*>(table);
-    const size_t pbytes = (size_t)nprob * sizeof(TrParams);
-    if (hipMemcpyAsync(dev, h.p, pbytes, hipMemcpyHostToDevice, stream) != hipSuccess ||
-        hipMemcpyAsync(dev + (pbytes + 15) / 16 * 16, h.first, (size_t)(nprob + 1) * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess)
-        return fail(ADCDIFF_E_LAUNCH, "gemm_tr_grouped: copying the problem table failed");
+    g.nprob = nprob;
     constexpr int smem = 2 * 32768;
     static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tr_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm_tr: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
-    TrGroup g{reinterpret_cast<const TrParams*>(dev), reinterpret_cast<const int*>(dev + (pbytes + 15) / 16 * 16), nprob};
     TimingScope ts(ADCDIFF_KIND_GEMM_BF16, tiles * 128, 128, 0, flops, bytes, stream);
     hipLaunchKernelGGL(gemm_tr_grouped_kernel, dim3((unsigned)tiles), dim3(256), smem, stream, g);
     return check_launch("gemm_tr_grouped");

@@ -175,10 +175,15 @@ struct ColsumItem {
     int first_block;      // prefix of 3 * ceil(C / 64) over the earlier items
 };
 constexpr int COLSUM_MAX_ITEMS = 32;
+struct ColsumTable {      // travels as the kernel's argument (2.6 KB): no copy to the device, nothing to keep alive
+    ColsumItem items[COLSUM_MAX_ITEMS];
+    int n;
+};
 
-__global__ __launch_bounds__(256) void colsum_batched_kernel(const ColsumItem* __restrict__ items, int n_items) {
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const ColsumTable tab) {
     __shared__ float red[16][64];
-    int lo = 0, hi = n_items - 1;
+    const ColsumItem* const items = tab.items;
+    int lo = 0, hi = tab.n - 1;
     const int blk = (int)blockIdx.x;
     while (lo < hi) {   // last item whose first block <= blk (workgroup-uniform)
         const int mid = (lo + hi + 1) >> 1;
@@ -338,7 +343,8 @@ static GnBwdGeom gn_bwd_geom(int rows, int C) {
 static size_t gn_bwd_part_bytes(int rows, int C) { return round_up((size_t)gn_bwd_geom(rows, C).nby * 3 * C * 4, 256); }
 
 struct ColsumQueue {
-    ColsumItem items[COLSUM_MAX_ITEMS];
+    ColsumTable tab;
+    ColsumItem (&items)[COLSUM_MAX_ITEMS] = tab.items;
     int n = 0, blocks = 0;
     Bump parts{nullptr, 0};   // the partial rows of every launch stay until the batched column sums have run
 };
@@ -374,13 +380,12 @@ static int gn_silu_bwd(const float* u, long ldu, const float* dA, long ldda, int
     return check_launch("gn_silu_bwd");
 }
 
-// the queued column sums in one launch; `table` is device memory for COLSUM_MAX_ITEMS items
-static int colsum_flush(ColsumQueue& cq, void* table, hipStream_t st) {
+// the queued column sums in one launch
+static int colsum_flush(ColsumQueue& cq, hipStream_t st) {
     if (cq.n == 0) return ADCDIFF_OK;
-    if (hipMemcpyAsync(table, cq.items, (size_t)cq.n * sizeof(ColsumItem), hipMemcpyHostToDevice, st) != hipSuccess)
-        return fail(ADCDIFF_E_LAUNCH, "unet_backward: copying the column-sum table failed");
+    cq.tab.n = cq.n;
     TimingScope ts(ADCDIFF_KIND_OTHER, cq.n, 0, 0, 0.0, (double)cq.parts.off, st);
-    hipLaunchKernelGGL(colsum_batched_kernel, dim3((unsigned)cq.blocks), dim3(256), 0, st, reinterpret_cast<const ColsumItem*>(table), cq.n);
+    hipLaunchKernelGGL(colsum_batched_kernel, dim3((unsigned)cq.blocks), dim3(256), 0, st, cq.tab);
     cq.n = 0; cq.blocks = 0;
     return check_launch("colsum_batched");
 }
@@ -637,11 +642,9 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
     DwQueue dwq;
     DwQueue* const q_dw = direct && debug_value(DBG_TRAIN_GROUP_DW) != 0 ? &dwq : nullptr;
     void* dY_keep[10][2] = {};
-    void* dw_table = nullptr;
     if (direct) {
         for (int i = 0; i < 10; ++i)
             for (int k = 0; k < 2; ++k) dY_keep[i][k] = ws.take((size_t)Bp * n->blk[i].cout * e);
-        dw_table = ws.take(gemm_tr_table_bytes(TR_MAX_GROUP));
         // rows B .. Bp of these operands are read by the d(x) products (M = Bp): zero, as the cast kernels left them
         if (!dry && Bp > B)
             for (int i = 0; i < 10; ++i)
@@ -659,7 +662,6 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         }
         cq.parts = Bump(ws.take(need), need);
     }
-    void* const colsum_table = ws.take((size_t)COLSUM_MAX_ITEMS * sizeof(ColsumItem));
     // direct path: the bf16 copy of a finished d(block output) / d(h1) and its column sums (bias gradients) come out of the
     // GroupNorm backward kernel that finishes it, instead of a cast pass over it
     const bool fuse_cast = direct && debug_value(DBG_TRAIN_FUSE_CAST) != 0;
@@ -823,7 +825,7 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
             col += b.part_c[k];
         }
     }
-    if (q_dw && !dry) TRY(gemm_tr_grouped(dwq.probs, dwq.n, dw_table, st));
+    if (q_dw && !dry) TRY(gemm_tr_grouped(dwq.probs, dwq.n, st));
     // ---- time branch: tb_table = SiLU(te_table) Wtp_all^T + btp_all; te_table = te_hidden W2^T + b2; te_hidden = SiLU(te_pre);
     //      te_pre = sinusoid W1^T + b1 (all float32, M = Tp rows of which only the drawn timesteps carry gradient)
     ws.off = mark;
@@ -943,6 +945,6 @@ static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adc
         RUN(cast_transpose<float>(n->sin_table, H, Tp, Tp, H, ADCDIFF_F32, nullptr, 0, sinT, Tp, nullptr, st));
         RUN(gemm_simple(ADCDIFF_F32, dPRE_t, Tp, sinT, Tp, 4 * H, 0, H, Tp, gr->time_lin1_w, H, st));
     }
-    if (!dry) TRY(colsum_flush(cq, colsum_table, st));
+    if (!dry) TRY(colsum_flush(cq, st));
     return ADCDIFF_OK;
 }

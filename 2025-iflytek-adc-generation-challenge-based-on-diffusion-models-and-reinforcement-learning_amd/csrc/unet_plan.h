@@ -19,8 +19,7 @@ struct TrProblem {
     int M, N, K;
 };
 constexpr int TR_MAX_GROUP = 64;
-size_t gemm_tr_table_bytes(int nprob);
-int gemm_tr_grouped(const TrProblem* probs, int nprob, void* table, hipStream_t stream);
+int gemm_tr_grouped(const TrProblem* probs, int nprob, hipStream_t stream);
 int groupnorm_silu(const float* x, int ldx, int M, int C, int groups, const float* gamma, const float* beta, float eps,
                    int out_dtype, void* out, int ldo, void* raw_out, int ldraw, hipStream_t stream, float drop_p = 0.0f,
                    uint64_t drop_seed = 0, uint32_t drop_layer = 0);
