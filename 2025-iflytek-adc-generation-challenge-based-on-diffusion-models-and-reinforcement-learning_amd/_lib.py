@@ -129,6 +129,7 @@ SIGNATURES = {
     "adcdiff_debug_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
     "adcdiff_timing_begin": (C.c_int, [C.c_int]),
     "adcdiff_timing_end": (C.c_int, [C.POINTER(TimingRecord), C.c_int, C.POINTER(C.c_int)]),
+    "adcdiff_matrix_core_probe": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -171,3 +172,10 @@ def debug_get(key):
     v = C.c_longlong()
     check(load().adcdiff_debug_get(key.encode(), C.byref(v)))
     return int(v.value)
+
+
+def matrix_core_probe(iters=20000, launches=40):
+    """(TFLOP/s, shader clock in MHz) that the matrix cores of the current GPU sustain on register operands (adcdiff_matrix_core_probe)."""
+    tf, mhz = C.c_double(), C.c_double()
+    check(load().adcdiff_matrix_core_probe(int(iters), int(launches), C.byref(tf), C.byref(mhz)))
+    return float(tf.value), float(mhz.value)

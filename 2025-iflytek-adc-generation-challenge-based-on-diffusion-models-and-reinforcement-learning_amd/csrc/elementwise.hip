@@ -392,6 +392,7 @@ const DebugEntry kDebug[DBG_NKEYS] = {
     {"gemm_cl", 1},           // 0: never the loader-wave variant of the one-wave kernel
     {"gemm_splitk", 1},       // 0: never the few-row kernel that splits K over workgroups (results then bit-identical to the tile kernels)
     {"gemm_pf_w", 0},         // 1: the four-wave kernel's W loaders prefetch their W rows into L2 as well
+    {"gemm_stagger", 0},      // four-wave kernel: start delay per XCD index of each CU's first workgroup, in 10 ns ticks (0 = none)
     {"step_fold", 1},         // 0: the reverse step as a launch of its own instead of the output GEMM's epilogue
     {"train_transpose", 0},   // 1: backward products on transposed copies (the NT kernel) instead of gemm_tr
     {"train_group_dw", 1},    // 0: every weight-gradient product of the backward pass as a launch of its own
@@ -809,4 +810,79 @@ extern "C" int adcdiff_timing_end(adcdiff_timing_record* out, int capacity, int*
     }
     *count = n;
     return ADCDIFF_OK;
+}
+
+// ---- what the matrix cores sustain inside the power limit ------------------------------------------------------------------
+// 64 v_mfma_f32_16x16x32_bf16 per iteration and wave on register operands with random signs, exponents and mantissas (no memory
+// traffic at all), one wave per SIMD holding 256 accumulator registers, as in the four-wave GEMM.  The shader clock (s_memtime
+// ticks per 10 ns of the constant 100 MHz counter) is read by every workgroup.
+namespace adcdiff {
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float probe_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 1) void matrix_core_probe_kernel(float* out, int iters, long long* ticks) {
+    probe_bf16x8 a[8], b[8];
+    for (int i = 0; i < 8; ++i)
+        for (int k = 0; k < 8; ++k) {   // |x| in [0.25, 4)
+            unsigned h = (threadIdx.x * 64 + i * 8 + k + blockIdx.x * 16384) * 2654435761u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            a[i][k] = __builtin_bit_cast(__bf16, (unsigned short)((h & 0x807f) | ((125 + ((h >> 8) & 3)) << 7)));
+            b[i][k] = __builtin_bit_cast(__bf16, (unsigned short)(((h >> 16) & 0x807f) | ((125 + ((h >> 28) & 3)) << 7)));
+        }
+    const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    probe_f32x4 acc[8][8] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float s = 0.0f;
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][3];
+    const long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) { ticks[blockIdx.x * 2] = c1 - c0; ticks[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+}  // namespace adcdiff
+
+extern "C" int adcdiff_matrix_core_probe(int iters, int launches, double* tflops, double* clock_mhz) {
+    using namespace adcdiff;
+    if (iters <= 0 || launches <= 0 || !tflops || !clock_mhz) return fail(ADCDIFF_E_BADARG, "matrix_core_probe: iters=%d launches=%d", iters, launches);
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || cus <= 0) return fail(ADCDIFF_E_LAUNCH, "matrix_core_probe: device query: %s", hipGetErrorString(e));
+    float* out = nullptr;
+    long long* ticks = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = ADCDIFF_OK;
+    auto step = [&](hipError_t err, const char* what) {
+        if (rc == ADCDIFF_OK && err != hipSuccess) rc = fail(ADCDIFF_E_LAUNCH, "matrix_core_probe: %s: %s", what, hipGetErrorString(err));
+        return rc == ADCDIFF_OK;
+    };
+    if (step(hipMalloc(&out, (size_t)cus * 256 * sizeof(float)), "hipMalloc") && step(hipMalloc(&ticks, (size_t)cus * 16), "hipMalloc") &&
+        step(hipEventCreate(&e0), "hipEventCreate") && step(hipEventCreate(&e1), "hipEventCreate")) {
+        const int settle = launches / 4 + 1;   // untimed launches in front: the clock needs some milliseconds to settle
+        for (int w = 0; w < settle; ++w) hipLaunchKernelGGL(matrix_core_probe_kernel, dim3(cus), dim3(256), 0, nullptr, out, iters, ticks);
+        step(hipEventRecord(e0, nullptr), "hipEventRecord");
+        for (int w = 0; w < launches; ++w) hipLaunchKernelGGL(matrix_core_probe_kernel, dim3(cus), dim3(256), 0, nullptr, out, iters, ticks);
+        step(hipEventRecord(e1, nullptr), "hipEventRecord");
+        step(hipEventSynchronize(e1), "hipEventSynchronize");
+        float ms = 0.0f;
+        std::vector<long long> h((size_t)cus * 2);
+        if (step(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime") &&
+            step(hipMemcpy(h.data(), ticks, h.size() * sizeof(long long), hipMemcpyDeviceToHost), "hipMemcpy")) {
+            double mhz = 0.0;
+            for (int i = 0; i < cus; ++i) mhz += 100.0 * (double)h[2 * i] / (double)(h[2 * i + 1] > 0 ? h[2 * i + 1] : 1);
+            *clock_mhz = mhz / cus;
+            // per iteration and wave: 64 instructions of 2 * 16 * 16 * 32 flop
+            *tflops = 64.0 * 16384.0 * iters * 4.0 * cus * launches / ((double)ms * 1e-3) * 1e-12;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (out) (void)hipFree(out);
+    if (ticks) (void)hipFree(ticks);
+    return rc;
 }

@@ -16,6 +16,7 @@
 // GroupNorm is applied by the producer, so no layer output is ever re-read just to be normalised.
 #include <cstdlib>
 #ifdef ADCDIFF_STAMPS
+#include <algorithm>
 #include <cstdio>
 #include <vector>
 #endif
@@ -60,6 +61,7 @@ struct GemmParams {
     long long split_k_bytes;     // byte offset along K of slice blockIdx.y (0 without split-K)
     long long split_out_stride;  // floats between the partial outputs of consecutive slices
     int pf_w;                    // four-wave kernel: prefetch the W rows as well (measurement switch)
+    int stagger;                 // four-wave kernel: start delay per XCD index of the first workgroup on each CU, in 10 ns ticks
     int sk_splits;               // few-row split-K kernel: workgroups per output tile (0 = not used)
     float* sk_part;              // its partial accumulators, [tiles][sk_splits][TM * TN][64 lanes][4] floats
     unsigned* sk_cnt;            // its arrival counters, one per output tile; zero before and after every launch
@@ -161,6 +163,41 @@ struct Epilogue {
                 if (g < p.n_gn) val = *reinterpret_cast<const f32x4*>(((vec - 1) & 1 ? p.gn[g].beta : p.gn[g].gamma) + n0 + c);
             }
             *reinterpret_cast<f32x4*>(prm + vec * BN + c) = val;
+        }
+    }
+
+    // The same in two halves, for a kernel whose main loop leaves registers free: the loads go out in front of the main loop and
+    // their round trip runs under it; the values reach LDS behind it (followed by the caller's barrier).
+    static constexpr int NPV = (5 * BN / 4 + NT - 1) / NT;
+    struct ParamRegs { f32x4 v[NPV], rb; };
+    static __device__ __forceinline__ void load_params(const GemmParams& p, int n0, int tid, ParamRegs& pr) {
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        pr.rb = zero;
+        // the five sources in scalar registers first, chosen by comparisons: an index into p.gn (or a choice between the fields'
+        // addresses) would be resolved by a vector load from the argument block, a round trip in front of the load proper
+        const float *s0 = p.bias, *s1 = p.gn[0].gamma, *s2 = p.gn[0].beta, *s3 = p.gn[1].gamma, *s4 = p.gn[1].beta;
+        asm volatile("" : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4));
+#pragma unroll
+        for (int i = 0; i < NPV; ++i) {
+            const int idx = tid + i * NT;
+            const int vec = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
+            const float* src = vec == 0 ? s0 : vec == 1 ? s1 : vec == 2 ? s2 : vec == 3 ? s3 : s4;
+            const bool have = idx < 5 * BN / 4 && (vec == 0 ? p.bias != nullptr : (vec - 1) >> 1 < p.n_gn);
+            typedef const __attribute__((address_space(1))) f32x4* gvec_t;   // global, not generic: the empty asm hides where s0..s4 point
+            if (have) pr.v[i] = *(gvec_t)(src + n0 + c);
+            else pr.v[i] = zero;
+            if (i == 0 && vec == 0 && p.rowbias && !p.rowbias_idx && p.ldrb == 0) pr.rb = *reinterpret_cast<const f32x4*>(p.rowbias + n0 + c);
+        }
+    }
+    static __device__ __forceinline__ void store_params(const GemmParams& p, int tid, float* prm, const ParamRegs& pr) {
+#pragma unroll
+        for (int i = 0; i < NPV; ++i) {
+            const int idx = tid + i * NT;
+            f32x4 val = pr.v[i];
+            if (i == 0 && idx < BN / 4 && p.rowbias && !p.rowbias_idx && p.ldrb == 0) {   // as stage_params: bias, then the broadcast row
+                val[0] += pr.rb[0]; val[1] += pr.rb[1]; val[2] += pr.rb[2]; val[3] += pr.rb[3];
+            }
+            if (idx < 5 * BN / 4) *reinterpret_cast<f32x4*>(prm + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4) = val;
         }
     }
 
@@ -467,24 +504,44 @@ struct Epilogue {
         bf16x8 res_bf;
         float res_f[8];
     };
-    static __device__ __forceinline__ void step_load(const GemmParams& p, const float* stage, int h, int st, int m0, int wm, int rr, int cg,
-                                                     long col, StepIn& in) {
-        const T* const resp = reinterpret_cast<const T*>(p.residual);
-        const bool row_rb = p.rowbias != nullptr && (p.rowbias_idx != nullptr || p.ldrb != 0);
-        const int crow = st * RPS + rr;
-        const long row = m0 + wm * WTM + h * CH + crow;
+    // The step's inputs from global memory (latencies of microseconds under load): the row's bias-table row and the residual.
+    // SIDE: what the kernel knows at compile time about these two inputs.  0: nothing (both tested at run time); 1: no per-row bias
+    // and no residual; 2: no per-row bias, a residual.  A load that is skipped at run time leaves the compiler with registers that
+    // "may" still be the target of a load in flight, and it then waits for ALL loads (vmcnt(0)) wherever one of them is reused:
+    // a look-ahead only works where the loads are unconditional.
+    template <int SIDE>
+    static __device__ __forceinline__ bool has_row_rb(const GemmParams& p) {
+        return SIDE == 0 && p.rowbias != nullptr && (p.rowbias_idx != nullptr || p.ldrb != 0);
+    }
+    template <int SIDE>
+    static __device__ __forceinline__ bool has_residual(const GemmParams& p) { return SIDE == 0 ? p.residual != nullptr : SIDE == 2; }
+
+    template <int SIDE = 0>
+    static __device__ __forceinline__ void rowbias_load(const GemmParams& p, int h, int st, int m0, int wm, int rr, long col, StepIn& in) {
+        const long row = m0 + wm * WTM + h * CH + st * RPS + rr;
         const long lrow = row < p.m_valid ? row : 0;    // dead rows read row 0's side inputs (always valid) and store nothing
-        load8(stage + crow * LDW + cg * 8, in.v);
-        if (row_rb) {
+        if (has_row_rb<SIDE>(p)) {
             long ridx = p.rowbias_idx ? (long)p.rowbias_idx[lrow] : lrow;
             if (p.rowbias_rows > 0) ridx = ridx < 0 ? 0 : ridx >= p.rowbias_rows ? p.rowbias_rows - 1 : ridx;   // never read outside the table
             load8(p.rowbias + ridx * p.ldrb + col, in.rb);
         }
-        if (resp) {
+    }
+    template <int SIDE = 0>
+    static __device__ __forceinline__ void residual_load(const GemmParams& p, int h, int st, int m0, int wm, int rr, long col, StepIn& in) {
+        const T* const resp = reinterpret_cast<const T*>(p.residual);
+        const long row = m0 + wm * WTM + h * CH + st * RPS + rr;
+        const long lrow = row < p.m_valid ? row : 0;
+        if (has_residual<SIDE>(p)) {
             const T* rp = resp + lrow * p.ldr + col;
             if constexpr (BF) in.res_bf = *reinterpret_cast<const bf16x8*>(rp);
             else load8(reinterpret_cast<const float*>(rp), in.res_f);
         }
+    }
+    static __device__ __forceinline__ void step_load(const GemmParams& p, const float* stage, int h, int st, int m0, int wm, int rr, int cg,
+                                                     long col, StepIn& in) {
+        load8(stage + (st * RPS + rr) * LDW + cg * 8, in.v);
+        rowbias_load(p, h, st, m0, wm, rr, col, in);
+        residual_load(p, h, st, m0, wm, rr, col, in);
     }
 
     template <bool PRM_IN_REGS>
@@ -547,10 +604,10 @@ struct Epilogue {
 
     // U consecutive steps finished together (U rows per lane): side inputs added row by row in the order of step_finish, then
     // every output of the U rows from one basic block.  For kernels whose GroupNorm groups never span two waves.
-    template <int U>
+    template <int U, int SIDE = 0>
     static __device__ __forceinline__ void finish_multi(const GemmParams& p, const StepIn (&in)[U], const float* prm, int h, int st0,
                                                         int m0, int wm, int wave, int rr, int cg, int bcol, long col, const float (&cb)[8]) {
-        const bool row_rb = p.rowbias != nullptr && (p.rowbias_idx != nullptr || p.ldrb != 0);
+        const bool row_rb = has_row_rb<SIDE>(p);
         float v[U][8];
         long row[U];
         bool live[U];
@@ -567,7 +624,7 @@ struct Epilogue {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[u][k] += in[u].rb[k];
         }
-        if (p.residual) {
+        if (has_residual<SIDE>(p)) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -622,7 +679,7 @@ struct Epilogue {
     // from the instruction cache -- for the one-workgroup-per-CU kernel, whose waves otherwise all fetch ~100 KB of
     // straight-line code cold.  Only the accumulator -> LDS copy needs compile-time register indices, hence the switch.
     // Unrolled (the kernels with 3-4 workgroups per CU): steps overlap each other's loads, parameters sit in registers.
-    template <bool ROLLED, int U = 1>
+    template <bool ROLLED, int U = 1, int SIDE = 0>
     static __device__ __forceinline__ void run(const acc_t (&acc)[TM][TN], const GemmParams& p, int m0, int n0, int wm, int wn, int wave,
                                                int lane, float* smem_epi, float* prm, float* xch_base) {
         float* const stage = smem_epi + wave * (CH * LDW);
@@ -641,18 +698,41 @@ struct Epilogue {
         }
         if constexpr (ROLLED) {
             int step_id = 0;
+            StepIn ahead[U];
+            // Chunk 0 is staged in front of the loop and chunk h + 1 at the end of iteration h (a wave's LDS accesses execute in
+            // order): the registers of chunk 0's accumulators are then free throughout the loop.
+            stage_chunk<0>(acc, stage, crow0, ccol);
 #pragma unroll 1
             for (int h = 0; h < NCHUNK; ++h) {
-                switch (h) {
-                    case 0: stage_chunk<0>(acc, stage, crow0, ccol); break;
-                    case 1: stage_chunk<1>(acc, stage, crow0, ccol); break;
-                    case 2: stage_chunk<2>(acc, stage, crow0, ccol); break;
-                    default: stage_chunk<3>(acc, stage, crow0, ccol); break;
-                }
+#ifdef ADCDIFF_STAMPS
+                if (U > 1 && NT == 256 && p.stamps && lane == 0 && blockIdx.x < 8192)
+                    p.stamps[((long)blockIdx.x * 4 + wave) * 16 + 5 + 2 * h] = __builtin_amdgcn_s_memrealtime();
+#endif
                 if constexpr (U == 1) {
 #pragma unroll 1
                     for (int st = 0; st < NSTEP; ++st, ++step_id)
                         step<false>(p, stage, prm, xch_base, h, st, step_id, m0, wm, wave, rr, cg, bcol, col, cb, g0, b0, g1, b1);
+                } else if constexpr (NSTEP == 2 * U && SIDE != 0) {
+                    // Two batches per chunk, the residual fetched one batch ahead (that of batch 0 of chunk h + 1 during batch 1
+                    // of chunk h): a wave alone on its SIMD would otherwise sit through a memory round trip per batch.
+                    // Past the last chunk the look-ahead re-reads the last chunk's rows (cached, unused).
+                    if (h == 0) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) residual_load<SIDE>(p, 0, u, m0, wm, rr, col, ahead[u]);
+                    }
+                    StepIn in[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) residual_load<SIDE>(p, h, U + u, m0, wm, rr, col, in[u]);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) load8(stage + (u * RPS + rr) * LDW + cg * 8, ahead[u].v);
+                    finish_multi<U, SIDE>(p, ahead, prm, h, 0, m0, wm, wave, rr, cg, bcol, col, cb);
+                    const int hn = h + 1 < NCHUNK ? h + 1 : h;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) residual_load<SIDE>(p, hn, u, m0, wm, rr, col, ahead[u]);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) load8(stage + ((U + u) * RPS + rr) * LDW + cg * 8, in[u].v);
+                    finish_multi<U, SIDE>(p, in, prm, h, U, m0, wm, wave, rr, cg, bcol, col, cb);
+                    step_id += 2 * U;
                 } else {
                     static_assert(NSTEP % U == 0, "steps per chunk must be a multiple of the load batch");
 #pragma unroll 1
@@ -662,6 +742,16 @@ struct Epilogue {
                         for (int u = 0; u < U; ++u) step_load(p, stage, h, st + u, m0, wm, rr, cg, col, in[u]);
                         finish_multi<U>(p, in, prm, h, st, m0, wm, wave, rr, cg, bcol, col, cb);
                     }
+                }
+#ifdef ADCDIFF_STAMPS
+                if (U > 1 && NT == 256 && p.stamps && lane == 0 && blockIdx.x < 8192)
+                    p.stamps[((long)blockIdx.x * 4 + wave) * 16 + 6 + 2 * h] = __builtin_amdgcn_s_memrealtime();
+#endif
+                switch (h) {   // only the accumulator -> LDS copy needs compile-time register indices
+                    case 0: stage_chunk<1>(acc, stage, crow0, ccol); break;
+                    case 1: stage_chunk<2>(acc, stage, crow0, ccol); break;
+                    case 2: stage_chunk<3>(acc, stage, crow0, ccol); break;
+                    default: break;
                 }
             }
         } else {
@@ -1208,7 +1298,7 @@ __global__ __launch_bounds__(512, 2) void gemm256r_bf16_kernel(const GemmParams 
 // bit-identical between the tilings.  Not for split-K launches.
 #include "w4_mainloop.inc"
 
-template <int EPI_U>
+template <int EPI_U, int SIDE>
 __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams p) {
     typedef bf16_t T;
     constexpr int BN = 256, WTM = 128, WTN = 128, TM = 8, TN = 8, STAGE_BYTES = 65536;
@@ -1223,10 +1313,22 @@ __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams 
 
     int bid = blockIdx.x;
     const int nwg = gridDim.x;
+#ifdef ADCDIFF_STAMPS
+    const long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();
+#endif
+    // Every workgroup of a launch does the same work, so without help all CUs run their K loops together (HBM nearly idle) and
+    // then their epilogues together (every CU storing at once, the matrix cores idle).  Delaying the first workgroup of each CU
+    // by its XCD's index x `stagger` spreads the eight XCDs over the phase: one XCD stores while seven multiply.  The workgroups
+    // of one XCD stay together, because they share operand lines through that XCD's L2.
+    if (p.stagger > 0 && blockIdx.x < 256u && nwg > 256) {
+        const long long until = (long long)__builtin_amdgcn_s_memrealtime() + (long long)(blockIdx.x & 7u) * p.stagger;
+        while ((long long)__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    }
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int nidx = bid % p.ntn;
     const int m0 = (bid / p.ntn) * 256, n0 = nidx * BN;
-    Epi::stage_params(p, n0, tid, prm);
+    typename Epi::ParamRegs pv;
+    Epi::load_params(p, n0, tid, pv);
 
     // Loader role: waves 0, 1 stage the A rows 128 (wave & 1) .. + 127 of the tile, waves 2, 3 the W rows.  Per K segment
     // {base, row pitch, K tiles, addressable bytes}; W is one segment.  The descriptor's size stops any stray access.
@@ -1290,8 +1392,24 @@ __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams 
                    "{v136}"(v_src0[0]), "{v137}"(v_src1[0]), "{v138}"(v_src0[1]), "{v139}"(v_src1[1]), "{v140}"(v_src0[2]), "{v141}"(v_src1[2]),
                    "{v144}"(v_pf[0]), "{v145}"(v_pf[1]), "{v146}"(v_pf[2])
                  : ADCDIFF_W4_CLOBBERS);
+#ifdef ADCDIFF_STAMPS
+    const long long rt1 = __builtin_amdgcn_s_memrealtime(), ct1 = __builtin_amdgcn_s_memtime();
+#endif
+    Epi::store_params(p, tid, prm, pv);
     __syncthreads();
-    Epi::template run<true, EPI_U>(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
+#ifdef ADCDIFF_STAMPS
+    const long long rtb = __builtin_amdgcn_s_memrealtime();
+#endif
+    Epi::template run<true, EPI_U, SIDE>(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
+#ifdef ADCDIFF_STAMPS
+    const long long rt2 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long rt3 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && blockIdx.x < 8192) {
+        long long* o = p.stamps + ((long)blockIdx.x * 4 + wave) * 16;
+        o[0] = rt0; o[1] = rt1; o[2] = rt2; o[3] = rt3; o[4] = rtb; o[13] = ct1 - ct0;
+    }
+#endif
 }
 
 // pipelined = the ring main loop (gemm256r_bf16_kernel), else the two-group phased loop
@@ -1341,16 +1459,63 @@ static int launch256(const GemmParams& p, bool pipelined, hipStream_t stream) {
     return check_launch("gemm256");
 }
 
-template <int EPI_U>
+// SIDE (see Epilogue::rowbias_load): 0 serves every launch; 1 / 2 know at compile time that there is no per-row bias and no /
+// a residual, which lets the epilogue fetch the residual one batch ahead
+template <int EPI_U, int SIDE = 0>
 static int launch256w(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = 2 * 65536 + Epilogue<bf16_t, 256, 256, 128, 128, 8, 8>::EXTRA_BYTES;
-    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256w_bf16_kernel<EPI_U>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256w_bf16_kernel<EPI_U, SIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (attr_err != hipSuccess) return fail(ADCDIFF_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmParams q = p;
     q.ntn = p.N / 256;
     q.pf_w = (int)debug_value(DBG_GEMM_PF_W);
+    q.stagger = (int)debug_value(DBG_GEMM_STAGGER);
     const int grid = (p.M / 256) * q.ntn;
-    hipLaunchKernelGGL(gemm256w_bf16_kernel<EPI_U>, dim3(grid), dim3(256), smem, stream, q);
+#ifdef ADCDIFF_STAMPS
+    static long long* dbuf = nullptr;
+    if (!dbuf) (void)hipMalloc(&dbuf, (size_t)8192 * 64 * 8);
+    q.stamps = dbuf;
+#endif
+    hipLaunchKernelGGL((gemm256w_bf16_kernel<EPI_U, SIDE>), dim3(grid), dim3(256), smem, stream, q);
+#ifdef ADCDIFF_STAMPS
+    {
+        // measurement build: the 10th launch is dissected (100 MHz constant clock, 10 ns units): per round of 256 workgroups (by
+        // start order) the mean time from kernel start to the workgroup's start, its main phase (set-up + prologue + K loop), its
+        // epilogue, and the drain of its stores
+        static int calls = 0;
+        if (++calls % 10 == 0 && grid <= 8192) {
+            (void)hipDeviceSynchronize();
+            std::vector<long long> h((size_t)grid * 64);
+            (void)hipMemcpy(h.data(), q.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+            std::vector<std::pair<long long, int>> order;
+            long long t0 = 1LL << 62, t_end = 0;
+            for (int b = 0; b < grid; ++b) { const long long* o = &h[(size_t)b * 64]; order.push_back({o[0], b}); if (o[0] < t0) t0 = o[0]; if (o[3] > t_end) t_end = o[3]; }
+            std::sort(order.begin(), order.end());
+            fprintf(stderr, "[stamps w4] N %d K tiles %d grid %d: kernel span %.1f us\n", p.N, p.nt_total, grid, (t_end - t0) / 100.0);
+            for (int r = 0; r * 256 < grid; ++r) {
+                double st = 0, mn = 0, ep = 0, dr = 0; int n = 0;
+                for (int k = r * 256; k < (r + 1) * 256 && k < grid; ++k, ++n) {
+                    const long long* o = &h[(size_t)order[k].second * 64];
+                    st += o[0] - t0; mn += o[1] - o[0]; ep += o[2] - o[1]; dr += o[3] - o[2];
+                }
+                fprintf(stderr, "[stamps w4]   round %d: start +%.1f us, main %.2f us, epilogue %.2f us, drain %.2f us\n", r, st / n / 100.0, mn / n / 100.0, ep / n / 100.0, dr / n / 100.0);
+                if (r == 1) {   // inside the epilogue, wave 0 of the round's workgroups: barrier, then per 32-row chunk (staging, steps)
+                    double seg[9] = {0}, clk = 0;
+                    for (int k = r * 256; k < (r + 1) * 256 && k < grid; ++k) {
+                        const long long* o = &h[(size_t)order[k].second * 64];
+                        clk += (double)o[13] / (double)(o[1] - o[0]);   // shader-clock ticks per 10 ns over the main phase
+                        seg[0] += o[4] - o[1];
+                        long long prev = o[4];
+                        for (int i = 0; i < 8; ++i) { seg[1 + i] += o[5 + i] - prev; prev = o[5 + i]; }
+                    }
+                    fprintf(stderr, "[stamps w4]     s_memtime rate over the main phase %.0f MHz; barrier %.2f us; chunks (stage, steps):", clk / n * 100.0, seg[0] / n / 100.0);
+                    for (int i = 0; i < 4; ++i) fprintf(stderr, " (%.2f, %.2f)", seg[1 + 2 * i] / n / 100.0, seg[2 + 2 * i] / n / 100.0);
+                    fprintf(stderr, " us\n");
+                }
+            }
+        }
+    }
+#endif
     return check_launch("gemm256w");
 }
 
@@ -2085,7 +2250,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     // 8-wave kernel's epilogue is the faster one there and the main loop is short), or a hint / the debug switch gemm_w4 = 0
     // asks for one of the 8-wave kernels
     const bool w4_default = debug_value(DBG_GEMM_W4) != 0;
-    const bool w4_hint = a.tile_hint == 2564 || a.tile_hint == 2565 || a.tile_hint == 2566 || a.tile_hint == 2568;
+    const bool w4_hint = a.tile_hint >= 2564 && a.tile_hint <= 2568;
     const bool w4 = big && p.ksplit == 1 && p.nt_total >= 2 &&
                     (w4_hint || (w4_default && a.N >= 512 && a.tile_hint != 2560 && a.tile_hint != 2561 && a.tile_hint != 256));
     const int kind = a.dtype == ADCDIFF_F32 ? ADCDIFF_KIND_GEMM_F32 : w4 ? ADCDIFF_KIND_GEMM_BF16_W256 : big ? ADCDIFF_KIND_GEMM_BF16_T256 : ADCDIFF_KIND_GEMM_BF16;
@@ -2093,8 +2258,14 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
                    esz * ((double)a.M * ktot + (double)a.N * ktot) + (double)a.M * a.N * (nout + (a.residual ? esz : 0.0)), stream);
     if (big) {
         // measurement aids: 2565 / 2566 / 2568 = epilogue batches of 1 / 2 / 8 rows per lane
-        if (w4) return a.tile_hint == 2565 ? launch256w<1>(p, stream) : a.tile_hint == 2566 ? launch256w<2>(p, stream)
-                     : a.tile_hint == 2568 ? launch256w<8>(p, stream) : launch256w<4>(p, stream);
+        if (w4) {
+            if (a.tile_hint == 2565) return launch256w<1>(p, stream);
+            if (a.tile_hint == 2566) return launch256w<2>(p, stream);
+            if (a.tile_hint == 2568) return launch256w<8>(p, stream);
+            const bool row_rb = p.rowbias != nullptr && (p.rowbias_idx != nullptr || p.ldrb != 0);
+            if (row_rb || a.tile_hint == 2567) return launch256w<4, 0>(p, stream);
+            return p.residual ? launch256w<4, 2>(p, stream) : launch256w<4, 1>(p, stream);
+        }
         return launch256(p, pipelined, stream);
     }
     // few live rows (the generator's default batch is 32): the one-wave kernel, 32 or 64 rows and 32 columns per workgroup

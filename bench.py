@@ -486,6 +486,14 @@ def main():
             sampler_desc = "p_sample_loop (DDPM, linear beta 1e-4..2e-2)" if args.sampler == "ddpm" else "ddim_sample_loop (50 steps, eta 0)"
             per_unit_ms = round(elapsed / args.steps / nsteps * 1e3, 4)
         roofs["roofline"]["window"] = {"clean_ms": round(clean_ms, 4), "launches": len(recs), "per_event_cost_us": round(over * 1e3, 2)}
+        if roofs["roofline"]["bound"] == "mfma" and dtype == "bf16":
+            # the data sheet's peak assumes the top clock; what the matrix cores sustain inside the power limit on register operands
+            # with random bits (no memory traffic) is measured here, on this GPU, right behind the timed region
+            tf, mhz = _lib.matrix_core_probe(20000, 24)
+            roofs["roofline"]["sustained_matrix_rate"] = {
+                "what": "v_mfma_f32_16x16x32_bf16 on register operands, one wave per SIMD on every CU, ~0.4 s",
+                "tflops": round(tf, 1), "shader_clock_mhz": round(mhz), "frac_of_peak": round(tf / roofs["roofline"]["peak"], 4),
+                "achieved_over_sustained": round(roofs["roofline"]["achieved"] / tf, 4)}
         line = {
             "metric": metric, "value": round(samples / elapsed, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),

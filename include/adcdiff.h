@@ -357,6 +357,8 @@ int adcdiff_clip_adamw_step_noalloc(const adcdiff_opt_tensor* tensors, int n_ten
  *                        kernel-family switches of adcdiff_gemm's dispatch
  *   gemm_splitk (1)      0 = never the few-row kernel that splits K over workgroups (splitk_scratch is ignored): small batches are
  *                        then bit-identical to large ones
+ *   gemm_stagger (0)     four-wave 256 x 256 kernel: the first workgroup on each CU waits (its index mod 8) x this many 10 ns ticks
+ *                        before it starts, which keeps the eight XCDs' epilogues apart
  *   step_fold (1)        0 = the reverse step and encoder.0's GroupNorm as launches of their own in the sampling loops
  *   train_transpose (0)  1 = backward products on transposed copies instead of adcdiff_gemm_tr
  *   train_group_dw (1)   0 = every weight-gradient product of adcdiff_unet_backward as a launch of its own (split over the batch,
@@ -388,6 +390,14 @@ typedef struct adcdiff_timing_record {
 } adcdiff_timing_record;
 int adcdiff_timing_begin(int max_records);
 int adcdiff_timing_end(adcdiff_timing_record* out, int capacity, int* count);
+
+/* What the matrix cores of the current GPU sustain inside its power limit; no counterpart in the reference.  Runs `launches`
+ * launches (after launches / 4 + 1 untimed ones) of a kernel that issues iters x 64 v_mfma_f32_16x16x32_bf16 per wave on register
+ * operands with random bits (no memory traffic), one wave per SIMD on every CU, on the null stream, and returns the rate in
+ * TFLOP/s and the mean shader clock in MHz.  The data sheet's dense bf16 rate assumes the top clock; under this load the clock
+ * settles lower, and a GEMM -- which also moves its operands -- cannot exceed the rate measured here.  Allocates and frees
+ * two small device buffers; synchronises the device. */
+int adcdiff_matrix_core_probe(int iters, int launches, double* tflops, double* clock_mhz);
 
 #ifdef __cplusplus
 }
