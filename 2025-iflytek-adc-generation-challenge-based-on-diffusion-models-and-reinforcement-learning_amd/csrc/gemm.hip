@@ -630,17 +630,18 @@ struct Epilogue {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[u][k] += BF ? (float)in[u].res_bf[k] : in[u].res_f[k];
         }
-        if (p.act == 1) {
+        // SIDE != 0 also says: no activation, no schedule update, no float32 output (the GEMMs inside the residual blocks)
+        if (SIDE == 0 && p.act == 1) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[u][k] = silu_f(v[u][k]);
         }
-        if (p.upd.kind != 0) {
+        if (SIDE == 0 && p.upd.kind != 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) apply_update(p.upd, v[u], live[u] ? row[u] : 0, col);
         }
-        if (p.out_f32) {
+        if (SIDE == 0 && p.out_f32) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (live[u]) store8<float>(p.out_f32 + (long)blockIdx.y * p.split_out_stride + row[u] * p.ldo_f32 + col, v[u]);
@@ -1460,7 +1461,7 @@ static int launch256(const GemmParams& p, bool pipelined, hipStream_t stream) {
 }
 
 // SIDE (see Epilogue::rowbias_load): 0 serves every launch; 1 / 2 know at compile time that there is no per-row bias and no /
-// a residual, which lets the epilogue fetch the residual one batch ahead
+// a residual (and no activation, schedule update or float32 output), which lets the epilogue fetch the residual one batch ahead
 template <int EPI_U, int SIDE = 0>
 static int launch256w(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = 2 * 65536 + Epilogue<bf16_t, 256, 256, 128, 128, 8, 8>::EXTRA_BYTES;
@@ -2264,6 +2265,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
             if (a.tile_hint == 2568) return launch256w<8>(p, stream);
             const bool row_rb = p.rowbias != nullptr && (p.rowbias_idx != nullptr || p.ldrb != 0);
             if (row_rb || a.tile_hint == 2567) return launch256w<4, 0>(p, stream);
+            if (p.act != 0 || p.upd.kind != 0 || p.out_f32) return launch256w<4, 0>(p, stream);
             return p.residual ? launch256w<4, 2>(p, stream) : launch256w<4, 1>(p, stream);
         }
         return launch256(p, pipelined, stream);
