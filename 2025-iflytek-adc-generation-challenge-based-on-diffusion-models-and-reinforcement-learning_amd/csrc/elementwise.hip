@@ -392,7 +392,6 @@ const DebugEntry kDebug[DBG_NKEYS] = {
     {"gemm_cl", 1},           // 0: never the loader-wave variant of the one-wave kernel
     {"gemm_splitk", 1},       // 0: never the few-row kernel that splits K over workgroups (results then bit-identical to the tile kernels)
     {"gemm_pf_w", 0},         // 1: the four-wave kernel's W loaders prefetch their W rows into L2 as well
-    {"gemm_stagger", 0},      // four-wave kernel: start delay per XCD index of each CU's first workgroup, in 10 ns ticks (0 = none)
     {"step_fold", 1},         // 0: the reverse step as a launch of its own instead of the output GEMM's epilogue
     {"train_transpose", 0},   // 1: backward products on transposed copies (the NT kernel) instead of gemm_tr
     {"train_group_dw", 1},    // 0: every weight-gradient product of the backward pass as a launch of its own

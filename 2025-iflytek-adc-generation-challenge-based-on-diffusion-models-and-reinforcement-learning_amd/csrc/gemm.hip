@@ -61,7 +61,6 @@ struct GemmParams {
     long long split_k_bytes;     // byte offset along K of slice blockIdx.y (0 without split-K)
     long long split_out_stride;  // floats between the partial outputs of consecutive slices
     int pf_w;                    // four-wave kernel: prefetch the W rows as well (measurement switch)
-    int stagger;                 // four-wave kernel: start delay per XCD index of the first workgroup on each CU, in 10 ns ticks
     int sk_splits;               // few-row split-K kernel: workgroups per output tile (0 = not used)
     float* sk_part;              // its partial accumulators, [tiles][sk_splits][TM * TN][64 lanes][4] floats
     unsigned* sk_cnt;            // its arrival counters, one per output tile; zero before and after every launch
@@ -1317,14 +1316,6 @@ __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams 
 #ifdef ADCDIFF_STAMPS
     const long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();
 #endif
-    // Every workgroup of a launch does the same work, so without help all CUs run their K loops together (HBM nearly idle) and
-    // then their epilogues together (every CU storing at once, the matrix cores idle).  Delaying the first workgroup of each CU
-    // by its XCD's index x `stagger` spreads the eight XCDs over the phase: one XCD stores while seven multiply.  The workgroups
-    // of one XCD stay together, because they share operand lines through that XCD's L2.
-    if (p.stagger > 0 && blockIdx.x < 256u && nwg > 256) {
-        const long long until = (long long)__builtin_amdgcn_s_memrealtime() + (long long)(blockIdx.x & 7u) * p.stagger;
-        while ((long long)__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
-    }
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     const int nidx = bid % p.ntn;
     const int m0 = (bid / p.ntn) * 256, n0 = nidx * BN;
@@ -1470,7 +1461,6 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     q.ntn = p.N / 256;
     q.pf_w = (int)debug_value(DBG_GEMM_PF_W);
-    q.stagger = (int)debug_value(DBG_GEMM_STAGGER);
     const int grid = (p.M / 256) * q.ntn;
 #ifdef ADCDIFF_STAMPS
     static long long* dbuf = nullptr;

@@ -350,15 +350,13 @@ int adcdiff_clip_adamw_step_noalloc(const adcdiff_opt_tensor* tensors, int n_ten
  *   tile_hints (0)       1 = honour adcdiff_gemm_args.tile_hint: 128 / 256 force that tile kernel where the shape allows (256 =
  *                        the eight-wave 256 x 256 kernel, 2560 / 2561 its phased / ring main loop, 2564 the four-wave 256 x 256
  *                        kernel with the assembly main loop, 2565 / 2566 / 2568 the same with epilogue batches of 1 / 2 / 8
- *                        rows); 1 / 3 the 128-row kernel with one LDS stage / the three-stage ring; 32 the one-wave kernel,
+ *                        rows, 2567 the same without the epilogue variants specialised on the launch's side inputs); 1 / 3 the 128-row kernel with one LDS stage / the three-stage ring; 32 the one-wave kernel,
  *                        325 its variant with loader waves, 327 the split-K variant (needs splitk_scratch)
  *   gemm_tile (0)        128 / 256 / 2561: as the hint of that value, for every bf16 launch
  *   gemm_ring (0), gemm_ring2 (1), gemm_ring_max (512), gemm_w4 (1), gemm_w1 (1), gemm_w1_rows (1024), gemm_cl (1)
  *                        kernel-family switches of adcdiff_gemm's dispatch
  *   gemm_splitk (1)      0 = never the few-row kernel that splits K over workgroups (splitk_scratch is ignored): small batches are
  *                        then bit-identical to large ones
- *   gemm_stagger (0)     four-wave 256 x 256 kernel: the first workgroup on each CU waits (its index mod 8) x this many 10 ns ticks
- *                        before it starts, which keeps the eight XCDs' epilogues apart
  *   step_fold (1)        0 = the reverse step and encoder.0's GroupNorm as launches of their own in the sampling loops
  *   train_transpose (0)  1 = backward products on transposed copies instead of adcdiff_gemm_tr
  *   train_group_dw (1)   0 = every weight-gradient product of adcdiff_unet_backward as a launch of its own (split over the batch,

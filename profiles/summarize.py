@@ -36,7 +36,11 @@ with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent"])
     for r in rows:
-        w.writerow([short(r["Name"]), r["Calls"], "%.3f" % (int(r["TotalDurationNs"]) / 1e6), "%.2f" % (float(r["AverageNs"]) / 1e3),
+        label = short(r["Name"])
+        if "gemm256w" in r["Name"]:   # template arguments <epilogue batch, side inputs known at compile time>
+            label += " general epilogue" if ", 0>" in r["Name"] or "Li0EE" in r["Name"] else \
+                     " residual look-ahead" if ", 2>" in r["Name"] or "Li2EE" in r["Name"] else " no side inputs"
+        w.writerow([label, r["Calls"], "%.3f" % (int(r["TotalDurationNs"]) / 1e6), "%.2f" % (float(r["AverageNs"]) / 1e3),
                     r["Percentage"]])
 
 traffic = {}

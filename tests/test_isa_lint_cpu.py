@@ -63,6 +63,7 @@ def test_loader_wave_kernel_isa(isa, bm, bn):
 
 def test_four_wave_kernel_has_no_scratch(isa):
     # epilogue batches of 1, 2 and 4 (the default) rows per lane; the batch of 8 is a measurement aid that spills in its epilogue
-    for u in (1, 2, 4):
-        _, scratch = _kernel(isa, "_ZN7adcdiff20gemm256w_bf16_kernelILi%dEEEvNS_10GemmParamsE" % u)
+    # (second parameter: what the epilogue knows about its side inputs; 1 and 2 are the variants that look ahead for the residual)
+    for u, side in ((1, 0), (2, 0), (4, 0), (4, 1), (4, 2)):
+        _, scratch = _kernel(isa, "_ZN7adcdiff20gemm256w_bf16_kernelILi%dELi%dEEEvNS_10GemmParamsE" % (u, side))
         assert scratch == 0

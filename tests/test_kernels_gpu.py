@@ -136,6 +136,32 @@ def test_gemm_256_tile_kernel_matches_128_tile_kernel(Ks, hint):
     assert np.abs(big[3].float().cpu().numpy()[:M - 9] - ref[:M - 9]).max() < 2.0 ** -8 * np.abs(ref).max() + 1e-5
 
 
+@pytest.mark.parametrize("residual", [False, True])
+@pytest.mark.parametrize("outputs", ["op", "gn", "op+gn", "op+gn+gn"])
+def test_four_wave_kernel_specialised_epilogues_match_the_general_one(residual, outputs):
+    """Launches without a per-row bias table, activation, schedule update or float32 output run the four-wave kernel in a variant
+    that knows so at compile time (and whether there is a residual) and fetches the residual one batch of rows ahead; hint 2567
+    forces the general variant.  Same arithmetic in the same order: every output agrees bit for bit, dead rows stay untouched."""
+    rng = np.random.default_rng(17 + residual)
+    M, N, Ks = 1024, 512, [256, 128]
+    bf = torch.bfloat16
+    As = [_t(rng.standard_normal((M, k)).astype(np.float32), bf) for k in Ks]
+    W = _t((rng.standard_normal((N, sum(Ks))) / np.sqrt(sum(Ks))).astype(np.float32) * 2, bf)
+    bias, row = _t(rng.standard_normal(N).astype(np.float32)), _t(rng.standard_normal(N).astype(np.float32))
+    gam, bet = _t((1 + 0.2 * rng.standard_normal(N)).astype(np.float32)), _t((0.1 * rng.standard_normal(N)).astype(np.float32))
+    kw = dict(bias=bias, rowbias=row, out_f32=False, out_op="op" in outputs, m_valid=M - 37, dtype="bf16",
+              gn=[(gam, bet, 16), (gam, bet, 128)][:outputs.count("gn")])   # rowbias without an index: one row for the whole batch
+    if residual:
+        kw["residual"] = _t(rng.standard_normal((M, N)).astype(np.float32), bf)
+    special = ops._raw_gemm(As, W, tile_hint=2564, **kw)
+    general = ops._raw_gemm(As, W, tile_hint=2567, **kw)
+    special = special if isinstance(special, (tuple, list)) else [special]
+    general = general if isinstance(general, (tuple, list)) else [general]
+    assert len(special) == len(general) == len(outputs.split("+"))
+    for a, b in zip(special, general):
+        assert torch.equal(a[:M - 37], b[:M - 37])
+
+
 def test_gemm_asymmetric_layout():
     """A = I against an asymmetric W catches a transposed or permuted accumulator map."""
     M = N = K = 128

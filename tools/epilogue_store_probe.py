@@ -20,11 +20,11 @@ variants = {
 for name, kw in variants.items():
     for mv in (None, 256):
         for _ in range(3):
-            ops._raw_gemm([A], W, dtype="bf16", tile_hint=2564, m_valid=mv, **kw)
+            ops._raw_gemm([A], W, dtype="bf16", m_valid=mv, **kw)
         torch.cuda.synchronize()
         with ops.timing(64) as tm:
             for _ in range(10):
-                ops._raw_gemm([A], W, dtype="bf16", tile_hint=2564, m_valid=mv, **kw)
+                ops._raw_gemm([A], W, dtype="bf16", m_valid=mv, **kw)
             torch.cuda.synchronize()
         ms = sorted(r["ms"] for r in tm.records[1:-1])
         print("%-40s m_valid %-6s %7.0f us" % (name, mv, ms[len(ms) // 2] * 1e3), flush=True)
