@@ -22,6 +22,7 @@
 #endif
 #include <type_traits>
 
+#include <atomic>
 #include "common.h"
 
 namespace adcdiff {
@@ -189,6 +190,9 @@ struct Epilogue {
         }
     }
     static __device__ __forceinline__ void store_params(const GemmParams& p, int tid, float* prm, const ParamRegs& pr) {
+        // vmcnt(0), unconditionally: the loads of load_params sit behind run-time conditions, and without a wait on every path the
+        // compiler keeps their registers as "possibly still being loaded" and waits for all loads wherever it reuses one of them
+        __builtin_amdgcn_s_waitcnt(0x0f70);
 #pragma unroll
         for (int i = 0; i < NPV; ++i) {
             const int idx = tid + i * NT;
@@ -1296,6 +1300,7 @@ __global__ __launch_bounds__(512, 2) void gemm256r_bf16_kernel(const GemmParams 
 // This wrapper computes the loop's inputs, pins them and the 64 accumulators to the registers the loop names, and runs the
 // shared epilogue on the result.  K order per accumulator = the other kernels' (32-wide steps in order), so results are
 // bit-identical between the tilings.  Not for split-K launches.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 #include "w4_mainloop.inc"
 
 template <int EPI_U, int SIDE>
@@ -1373,6 +1378,9 @@ __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams 
         if ((wrow0 >> 7) == half) v_pf[0] = (int)((unsigned)((wrow0 & 127) + lane) * (unsigned)seg_ld[0]);
     }
 
+#ifdef ADCDIFF_STAMPS
+    const long long rta = __builtin_amdgcn_s_memrealtime();
+#endif
     f32x4 acc[TM][TN];
     asm volatile(ADCDIFF_W4_MAINLOOP_ASM
                  : ADCDIFF_W4_OUTS(acc)
@@ -1399,7 +1407,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams 
     const long long rt3 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0 && blockIdx.x < 8192) {
         long long* o = p.stamps + ((long)blockIdx.x * 4 + wave) * 16;
-        o[0] = rt0; o[1] = rt1; o[2] = rt2; o[3] = rt3; o[4] = rtb; o[13] = ct1 - ct0;
+        o[0] = rt0; o[1] = rt1; o[2] = rt2; o[3] = rt3; o[4] = rtb; o[13] = ct1 - ct0; o[14] = rta;
     }
 #endif
 }
@@ -1491,15 +1499,16 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
                 }
                 fprintf(stderr, "[stamps w4]   round %d: start +%.1f us, main %.2f us, epilogue %.2f us, drain %.2f us\n", r, st / n / 100.0, mn / n / 100.0, ep / n / 100.0, dr / n / 100.0);
                 if (r == 1) {   // inside the epilogue, wave 0 of the round's workgroups: barrier, then per 32-row chunk (staging, steps)
-                    double seg[9] = {0}, clk = 0;
+                    double seg[9] = {0}, clk = 0, setup = 0;
                     for (int k = r * 256; k < (r + 1) * 256 && k < grid; ++k) {
                         const long long* o = &h[(size_t)order[k].second * 64];
                         clk += (double)o[13] / (double)(o[1] - o[0]);   // shader-clock ticks per 10 ns over the main phase
+                        setup += o[14] - o[0];
                         seg[0] += o[4] - o[1];
                         long long prev = o[4];
                         for (int i = 0; i < 8; ++i) { seg[1 + i] += o[5 + i] - prev; prev = o[5 + i]; }
                     }
-                    fprintf(stderr, "[stamps w4]     s_memtime rate over the main phase %.0f MHz; barrier %.2f us; chunks (stage, steps):", clk / n * 100.0, seg[0] / n / 100.0);
+                    fprintf(stderr, "[stamps w4]     set-up in front of the main loop %.2f us; s_memtime rate over the main phase %.0f MHz; barrier %.2f us; chunks (stage, steps):", setup / n / 100.0, clk / n * 100.0, seg[0] / n / 100.0);
                     for (int i = 0; i < 4; ++i) fprintf(stderr, " (%.2f, %.2f)", seg[1 + 2 * i] / n / 100.0, seg[2 + 2 * i] / n / 100.0);
                     fprintf(stderr, " us\n");
                 }
@@ -1525,7 +1534,6 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
 // to the tile's bytes (8 KiB 0.17 us, 12 KiB 0.24 us, 20 KiB 0.40 us); a four-stage ring, a third fewer scalar instructions and a
 // padded row pitch of W all left it where it was.
 // Fragments, K order and epilogue are those of the tile kernels: bit-identical results.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Piece m of a tile (1 KiB: 8 rows x 128 bytes) into LDS at the tile's stage + 1024 m.  M0 is written once per four pieces
 // (absolutely for m = 0, stepped by 4 KiB for m = 4, 8); the other three reach their slots through the instruction's offset

@@ -1,11 +1,14 @@
 """The launches of one denoising step at batch 65536 (bf16) in launch order: kind, shape, device time (mean over 8 steps).
-python tools/step_launches.py"""
+python tools/step_launches.py [debug_key=value ...]"""
 import sys
 import torch
 sys.path.insert(0, ".")
 import bench
 
 bench.load_runtime()
+for kv in sys.argv[1:]:
+    from adcdiff import _lib
+    _lib.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
 dev = torch.device("cuda", 0)
 model = bench.build_model("bf16", dev)
 B = 65536
