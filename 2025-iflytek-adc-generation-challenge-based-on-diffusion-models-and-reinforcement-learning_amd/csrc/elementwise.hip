@@ -387,11 +387,12 @@ const DebugEntry kDebug[DBG_NKEYS] = {
     {"gemm_ring2", 1},        // 0: never the two-stage ring of the 128-row kernels
     {"gemm_ring_max", 512},   // launches with at most this many 128-row workgroups take a ring of LDS stages
     {"gemm_w4", 1},           // 0: the eight-wave kernel instead of the four-wave 256-tile kernel
+    {"gemm_w4_min_n", 512},   // the narrowest layer (output columns) the four-wave kernel takes
     {"gemm_w1", 1},           // 0: the tile kernels instead of the one-wave kernels for few live rows
     {"gemm_w1_rows", 1024},   // live rows up to which the one-wave kernels are taken
     {"gemm_cl", 1},           // 0: never the loader-wave variant of the one-wave kernel
     {"gemm_splitk", 1},       // 0: never the few-row kernel that splits K over workgroups (results then bit-identical to the tile kernels)
-    {"gemm_pf_w", 0},         // 1: the four-wave kernel's W loaders prefetch their W rows into L2 as well
+    {"gemm_pf_w", 1},         // 0: the four-wave kernel's W loaders do not prefetch their W rows into L2 (the A loaders always prefetch theirs)
     {"step_fold", 1},         // 0: the reverse step as a launch of its own instead of the output GEMM's epilogue
     {"train_transpose", 0},   // 1: backward products on transposed copies (the NT kernel) instead of gemm_tr
     {"train_group_dw", 1},    // 0: every weight-gradient product of the backward pass as a launch of its own

@@ -61,7 +61,7 @@ struct GemmParams {
     int ksplit;                  // grid.y: K slices (1 without split-K)
     long long split_k_bytes;     // byte offset along K of slice blockIdx.y (0 without split-K)
     long long split_out_stride;  // floats between the partial outputs of consecutive slices
-    int pf_w;                    // four-wave kernel: prefetch the W rows as well (measurement switch)
+    int pf_w;                    // four-wave kernel: prefetch the W rows as well (debug switch gemm_pf_w, on by default)
     int sk_splits;               // few-row split-K kernel: workgroups per output tile (0 = not used)
     float* sk_part;              // its partial accumulators, [tiles][sk_splits][TM * TN][64 lanes][4] floats
     unsigned* sk_cnt;            // its arrival counters, one per output tile; zero before and after every launch
@@ -1658,6 +1658,12 @@ __global__ __launch_bounds__(64) void gemm_w1_bf16_kernel(const GemmParams p) {
     int slot = 0;   // stage of tile t: free (its fragments are in registers), takes tile t + D
     auto body = [&](auto SET) {
         constexpr int S = decltype(SET)::value;
+        // Every fragment read of tile t (issued during the previous body; the MFMAs below wait for them one by one) must have
+        // RETURNED before the first piece of tile t + D is issued into the same stage: with the last reads still queued in LDS
+        // and the piece served from a near cache, the piece overtook them now and then, and the rows 32 .. 39 or 48 .. 55 of the
+        // tile (the fragments read last, the pieces that land first) were multiplied with the data of tile t + D
+        // (1 forward pass in 50 to 1 in 3 at 1024 rows, by machine; tools/train_forward_repro.py).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         cursor();
         const unsigned dst = lds0 + (unsigned)slot * STAGE_BYTES;
         slot = slot == D - 1 ? 0 : slot + 1;
@@ -2251,7 +2257,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     const bool w4_default = debug_value(DBG_GEMM_W4) != 0;
     const bool w4_hint = a.tile_hint >= 2564 && a.tile_hint <= 2568;
     const bool w4 = big && p.ksplit == 1 && p.nt_total >= 2 &&
-                    (w4_hint || (w4_default && a.N >= 512 && a.tile_hint != 2560 && a.tile_hint != 2561 && a.tile_hint != 256));
+                    (w4_hint || (w4_default && a.N >= (int)debug_value(DBG_GEMM_W4_MIN_N) && a.tile_hint != 2560 && a.tile_hint != 2561 && a.tile_hint != 256));
     const int kind = a.dtype == ADCDIFF_F32 ? ADCDIFF_KIND_GEMM_F32 : w4 ? ADCDIFF_KIND_GEMM_BF16_W256 : big ? ADCDIFF_KIND_GEMM_BF16_T256 : ADCDIFF_KIND_GEMM_BF16;
     TimingScope ts(kind, a.M, a.N, ktot, 2.0 * a.M * a.N * ktot,
                    esz * ((double)a.M * ktot + (double)a.N * ktot) + (double)a.M * a.N * (nout + (a.residual ? esz : 0.0)), stream);

@@ -389,3 +389,16 @@ def test_custom_operators_through_the_dispatcher():
     torch.library.opcheck(torch.ops.adcdiff.latent_summary, (x,))
     # all 128 rows valid here: rows beyond m_valid are never written, so their (uninitialised) contents differ between two calls
     torch.library.opcheck(torch.ops.adcdiff.gemm, ([A], W, None, None, None, None, 0, True, False, [], [], [], 0, 0, 1e-5, 0, 0))
+
+
+def test_matrix_core_probe_reports_a_plausible_rate_and_clock():
+    """adcdiff_matrix_core_probe: bf16 matrix-core rate on register operands and the shader clock it ran at.  On an MI355X the rate
+    lies between a tenth of and the data-sheet 2.5 PFLOP/s, the clock between 0.5 and 2.5 GHz, and rate / (CUs x 4 SIMDs x 1024 flop
+    per cycle x clock) -- the share of cycles the matrix cores were issuing -- is at most 1."""
+    from adcdiff import _lib
+    tf, mhz = _lib.matrix_core_probe(2000, 8)
+    assert 250.0 < tf < 2600.0 and 500.0 < mhz < 2500.0
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert tf * 1e12 / (cus * 4 * 1024 * mhz * 1e6) < 1.02
+    with pytest.raises(adcdiff.AdcdiffError):
+        _lib.matrix_core_probe(0, 1)

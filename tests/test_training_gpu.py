@@ -495,3 +495,28 @@ def test_data_parallel_gradients_match_full_batch_reference(golden_tiny, tmp_pat
     assert checked >= 14
     t0, t1 = np.load(str(tmp_path / "t0.npy")), np.load(str(tmp_path / "t1.npy"))
     assert not np.array_equal(t0, t1)
+
+
+def test_taped_forward_reproduces_bit_for_bit_at_1024_rows():
+    """The training forward at 1024 rows runs its GEMMs on the one-wave kernel with sixteen row tiles per launch.  A piece of the next
+    tile issued into a ring stage whose fragment reads had not all returned overtook them on a lightly loaded chip: eight rows of a
+    tile were multiplied with the wrong K tile in one forward pass out of 3 to 50, by machine.  150 repetitions of one pass (same
+    inputs, same dropout seed) must give the same predicted noise bit for bit."""
+    dims = (512, 256, 512)
+    m = adcdiff.DiffusionModel(dict(input_dim=dims[0], hidden_dim=dims[1], output_dim=dims[2], compute_dtype="bf16", max_batch_size=4096))
+    m.model.train()
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    B = 1024
+    x = torch.randn(B, dims[0], generator=gen).cuda()
+    t = torch.randint(0, 1000, (B,), generator=gen).cuda()
+    dev = m.model._device()
+    eng = m.model.engine()
+    handle = eng.ensure(dev)
+    eng.train_workspace_for(B, dev)
+    first = None
+    for _ in range(150):
+        eps = torch.ops.adcdiff.unet_train_forward(handle.value, x, t, None, 0.1, 12345, m.model.output_dim, eng.workspace)
+        if first is None:
+            first = eps.clone()
+        else:
+            assert torch.equal(eps, first)
