@@ -67,6 +67,7 @@ struct GemmParams {
     unsigned* sk_cnt;            // its arrival counters, one per output tile; zero before and after every launch
 #ifdef ADCDIFF_STAMPS
     long long* stamps;
+    int* tile_stamps;   // four-wave kernel: 64 low words of the 100 MHz counter per workgroup (wave 0): entry, pieces issued, tile 0 landed, every tile's start, end
 #endif
 };
 
@@ -1302,6 +1303,9 @@ __global__ __launch_bounds__(512, 2) void gemm256r_bf16_kernel(const GemmParams 
 // bit-identical between the tilings.  Not for split-K launches.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #include "w4_mainloop.inc"
+#ifdef ADCDIFF_STAMPS
+#include "w4_mainloop_stamps.inc"   // python3 gen_w4_mainloop.py --stamps w4_mainloop_stamps.inc
+#endif
 
 template <int EPI_U, int SIDE>
 __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams p) {
@@ -1382,8 +1386,14 @@ __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams 
     const long long rta = __builtin_amdgcn_s_memrealtime();
 #endif
     f32x4 acc[TM][TN];
+#ifdef ADCDIFF_STAMPS
+    int tile_stamp;
+    asm volatile(ADCDIFF_W4S_MAINLOOP_ASM
+                 : ADCDIFF_W4_OUTS(acc), "={v147}"(tile_stamp)
+#else
     asm volatile(ADCDIFF_W4_MAINLOOP_ASM
                  : ADCDIFF_W4_OUTS(acc)
+#endif
                  : "{s40}"(seg_lo[0]), "{s41}"(seg_hi[0]), "{s42}"(seg_ld[0]), "{s43}"(seg_kt[0]), "{s44}"(seg_nrec[0]),
                    "{s45}"(seg_lo[1]), "{s46}"(seg_hi[1]), "{s47}"(seg_ld[1]), "{s48}"(seg_kt[1]), "{s49}"(seg_nrec[1]),
                    "{s50}"(seg_lo[2]), "{s51}"(seg_hi[2]), "{s52}"(seg_ld[2]), "{s53}"(seg_kt[2]), "{s54}"(seg_nrec[2]),
@@ -1391,9 +1401,12 @@ __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams 
                    "{v130}"(v_aoff0), "{v131}"(v_boff0), "{v132}"(v_aoff1), "{v133}"(v_boff1),
                    "{v136}"(v_src0[0]), "{v137}"(v_src1[0]), "{v138}"(v_src0[1]), "{v139}"(v_src1[1]), "{v140}"(v_src0[2]), "{v141}"(v_src1[2]),
                    "{v144}"(v_pf[0]), "{v145}"(v_pf[1]), "{v146}"(v_pf[2])
-                 : ADCDIFF_W4_CLOBBERS);
 #ifdef ADCDIFF_STAMPS
+                 : ADCDIFF_W4_CLOBBERS, "s88", "s89", "s90", "v148", "v149");
+    if (wave == 0 && blockIdx.x < 8192) p.tile_stamps[(long)blockIdx.x * 64 + lane] = tile_stamp;
     const long long rt1 = __builtin_amdgcn_s_memrealtime(), ct1 = __builtin_amdgcn_s_memtime();
+#else
+                 : ADCDIFF_W4_CLOBBERS);
 #endif
     Epi::store_params(p, tid, prm, pv);
     __syncthreads();
@@ -1472,8 +1485,11 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
     const int grid = (p.M / 256) * q.ntn;
 #ifdef ADCDIFF_STAMPS
     static long long* dbuf = nullptr;
+    static int* tbuf = nullptr;
     if (!dbuf) (void)hipMalloc(&dbuf, (size_t)8192 * 64 * 8);
+    if (!tbuf) (void)hipMalloc(&tbuf, (size_t)8192 * 64 * 4);
     q.stamps = dbuf;
+    q.tile_stamps = tbuf;
 #endif
     hipLaunchKernelGGL((gemm256w_bf16_kernel<EPI_U, SIDE>), dim3(grid), dim3(256), smem, stream, q);
 #ifdef ADCDIFF_STAMPS
@@ -1511,6 +1527,17 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
                     fprintf(stderr, "[stamps w4]     set-up in front of the main loop %.2f us; s_memtime rate over the main phase %.0f MHz; barrier %.2f us; chunks (stage, steps):", setup / n / 100.0, clk / n * 100.0, seg[0] / n / 100.0);
                     for (int i = 0; i < 4; ++i) fprintf(stderr, " (%.2f, %.2f)", seg[1 + 2 * i] / n / 100.0, seg[2 + 2 * i] / n / 100.0);
                     fprintf(stderr, " us\n");
+                    // inside the main loop (wave 0): lane 0 entry, 1 pieces of tiles 0 and 1 issued, 2 tile 0 landed, 3 .. the start of
+                    // every tile, then the end
+                    std::vector<int> ts((size_t)grid * 64);
+                    (void)hipMemcpy(ts.data(), q.tile_stamps, ts.size() * 4, hipMemcpyDeviceToHost);
+                    const int nst = p.nt_total + 4 < 64 ? p.nt_total + 4 : 64;
+                    std::vector<double> d(nst, 0.0);
+                    for (int k = r * 256; k < (r + 1) * 256 && k < grid; ++k)
+                        for (int i = 1; i < nst; ++i) d[i] += (unsigned)(ts[(size_t)order[k].second * 64 + i] - ts[(size_t)order[k].second * 64 + i - 1]);
+                    fprintf(stderr, "[stamps w4]     loop: issue %.2f, first tile lands %.2f, then per tile (us):", d[1] / n / 100.0, d[2] / n / 100.0);
+                    for (int i = 3; i < nst; ++i) fprintf(stderr, " %.2f", d[i] / n / 100.0);
+                    fprintf(stderr, "\n");
                 }
             }
         }

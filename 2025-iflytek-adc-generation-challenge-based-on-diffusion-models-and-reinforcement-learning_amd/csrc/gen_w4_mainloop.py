@@ -53,7 +53,7 @@ W_SET = [0, 64]
 STAGE = 0x10000
 PF = 4           # prefetch distance in K tiles beyond the tile being staged
 L = []
-ABLATE = set()   # lab only: "nodma", "noread", "nobar", "nowait", "dmafirsthalf", "nopf"
+ABLATE = set()   # lab only: "nodma", "noread", "nobar", "nowait", "dmafirsthalf", "nopf"; "stamps": the measurement build's loop
 
 
 def e(s):
@@ -165,6 +165,9 @@ def phase(s, read_stage, read_half, issue_stage, end):
         advance_cursor(pf=True)
         advance_cursor()
     for line in end:
+        if line == "STAMP":
+            stamp_keep()
+            continue
         if line.startswith("s_waitcnt vmcnt") and "nowait" in ABLATE:
             continue
         if line == "s_barrier" and "nobar" in ABLATE:
@@ -172,8 +175,26 @@ def phase(s, read_stage, read_half, issue_stage, end):
         e(line)
 
 
+def stamp_issue():
+    """measurement build: read the 100 MHz counter (a scalar load: it returns with the next lgkmcnt(0))"""
+    if "stamps" in ABLATE:
+        e("s_memrealtime s[88:89]")
+
+
+def stamp_keep():
+    """... and, behind that wait, keep its low word in lane s90 of v147 (one lane per stamp, at most 64)"""
+    if "stamps" in ABLATE:
+        e("v_mov_b32 v148, s88")                 # (v_writelane would need two scalar operands: one constant-bus read per instruction)
+        e("v_cmp_eq_u32 vcc, s90, v149")
+        e("v_cndmask_b32 v147, v147, v148, vcc")
+        e("s_add_u32 s90, s90, 1")
+        e("s_min_u32 s90, s90, 63")
+
+
 def tile(issue, last=False):
-    phase(0, "s68", 1, None, ["s_waitcnt lgkmcnt(0)"] if last else ["s_waitcnt lgkmcnt(0)", "s_waitcnt vmcnt(0)" if "nopf" in ABLATE else "s_waitcnt vmcnt(1)", "s_barrier"])
+    stamp_issue()   # at the start of a tile; kept at the end of its phase A
+    keep = ["s_waitcnt lgkmcnt(0)", "STAMP"] if "stamps" in ABLATE else ["s_waitcnt lgkmcnt(0)"]
+    phase(0, "s68", 1, None, keep if last else keep + ["s_waitcnt vmcnt(0)" if "nopf" in ABLATE else "s_waitcnt vmcnt(1)", "s_barrier"])
     if last:
         phase(1, None, 0, None, [])
     else:
@@ -189,6 +210,14 @@ def generate():
         if f.startswith("pf") and f[2:].isdigit():
             PF = int(f[2:])
     # ---- set-up
+    if "stamps" in ABLATE:   # lane 0: entry
+        e("s_mov_b32 s90, 0")
+        e("v_mov_b32 v147, 0")
+        e("v_mbcnt_lo_u32_b32 v149, -1, 0")
+        e("v_mbcnt_hi_u32_b32 v149, -1, v149")
+        stamp_issue()
+        e("s_waitcnt lgkmcnt(0)")
+        stamp_keep()
     e("s_mov_b32 s73, m0")
     e("s_mov_b32 s60, s40")
     e("s_mov_b32 s61, s41")
@@ -230,8 +259,16 @@ def generate():
             prefetch()        # tile 1 + PF; the youngest load, as in the loop
             advance_cursor(pf=True)
         advance_cursor()
+    if "stamps" in ABLATE:   # lane 1: the first two tiles' pieces are issued; lane 2: tile 0 has landed (behind the barrier)
+        stamp_issue()
+        e("s_waitcnt lgkmcnt(0)")
+        stamp_keep()
     e("s_waitcnt vmcnt(16)" if "nopf" in ABLATE else "s_waitcnt vmcnt(17)")
     e("s_barrier")
+    if "stamps" in ABLATE:
+        stamp_issue()
+        e("s_waitcnt lgkmcnt(0)")
+        stamp_keep()
     e("v_mov_b32 v128, v130")
     e("v_mov_b32 v129, v131")
     for r in range(16):
@@ -250,6 +287,10 @@ def generate():
     # ---- last two tiles: nothing left to issue
     tile(False)
     tile(False, last=True)
+    if "stamps" in ABLATE:   # last lane: the loop's end
+        stamp_issue()
+        e("s_waitcnt lgkmcnt(0)")
+        stamp_keep()
     # the last prefetch load may still be in flight: its result register is the compiler's again after this statement
     e("s_waitcnt vmcnt(0)")
     # the compiler does not know that MFMAs are still writing the accumulators it reads next
@@ -289,6 +330,15 @@ def main():
                 uid[0] = 0
                 generate()
                 emit(f, "W4LAB_" + name)
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "--stamps":
+        # the measurement build's loop (-DADCDIFF_STAMPS): the product's loop plus a time stamp per tile in v147 (s88..s90, v148, v149 scratch);
+        # the operand lists are those of w4_mainloop.inc
+        ABLATE.add("stamps")
+        generate()
+        with open(sys.argv[2], "w") as f:
+            f.write("// Generated by gen_w4_mainloop.py --stamps -- do not edit.\n")
+            emit(f, "ADCDIFF_W4S_MAINLOOP_ASM")
         return
     generate()
     out = sys.argv[1] if len(sys.argv) > 1 else "w4_mainloop.inc"
