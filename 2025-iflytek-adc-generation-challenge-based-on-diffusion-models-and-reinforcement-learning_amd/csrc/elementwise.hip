@@ -393,6 +393,7 @@ const DebugEntry kDebug[DBG_NKEYS] = {
     {"gemm_cl", 1},           // 0: never the loader-wave variant of the one-wave kernel
     {"gemm_splitk", 1},       // 0: never the few-row kernel that splits K over workgroups (results then bit-identical to the tile kernels)
     {"gemm_pf_w", 1},         // 0: the four-wave kernel's W loaders do not prefetch their W rows into L2 (the A loaders always prefetch theirs)
+    {"gemm_pf_next", 1},      // 0: the four-wave kernel does not touch its successor's first operand lines near the end of its epilogue
     {"step_fold", 1},         // 0: the reverse step as a launch of its own instead of the output GEMM's epilogue
     {"train_transpose", 0},   // 1: backward products on transposed copies (the NT kernel) instead of gemm_tr
     {"train_group_dw", 1},    // 0: every weight-gradient product of the backward pass as a launch of its own

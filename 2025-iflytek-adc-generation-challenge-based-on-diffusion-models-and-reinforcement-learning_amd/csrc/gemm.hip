@@ -62,6 +62,7 @@ struct GemmParams {
     long long split_k_bytes;     // byte offset along K of slice blockIdx.y (0 without split-K)
     long long split_out_stride;  // floats between the partial outputs of consecutive slices
     int pf_w;                    // four-wave kernel: prefetch the W rows as well (debug switch gemm_pf_w, on by default)
+    int pf_next;                 // four-wave kernel: workgroups resident at a time (one per CU), 0 = nothing is touched for the successor
     int sk_splits;               // few-row split-K kernel: workgroups per output tile (0 = not used)
     float* sk_part;              // its partial accumulators, [tiles][sk_splits][TM * TN][64 lanes][4] floats
     unsigned* sk_cnt;            // its arrival counters, one per output tile; zero before and after every launch
@@ -684,9 +685,11 @@ struct Epilogue {
     // from the instruction cache -- for the one-workgroup-per-CU kernel, whose waves otherwise all fetch ~100 KB of
     // straight-line code cold.  Only the accumulator -> LDS copy needs compile-time register indices, hence the switch.
     // Unrolled (the kernels with 3-4 workgroups per CU): steps overlap each other's loads, parameters sit in registers.
-    template <bool ROLLED, int U = 1, int SIDE = 0>
+    struct NoHook { __device__ __forceinline__ void operator()() const {} };
+    // last_chunk: called once, in the last chunk between its two batches (the variants with SIDE != 0 only)
+    template <bool ROLLED, int U = 1, int SIDE = 0, typename HOOK = NoHook>
     static __device__ __forceinline__ void run(const acc_t (&acc)[TM][TN], const GemmParams& p, int m0, int n0, int wm, int wn, int wave,
-                                               int lane, float* smem_epi, float* prm, float* xch_base) {
+                                               int lane, float* smem_epi, float* prm, float* xch_base, HOOK last_chunk = HOOK()) {
         float* const stage = smem_epi + wave * (CH * LDW);
         const int ccol = BF ? (lane & 15) : (lane & 31);
         const int crow0 = BF ? 4 * (lane >> 4) : 4 * (lane >> 5);
@@ -734,6 +737,7 @@ struct Epilogue {
                     const int hn = h + 1 < NCHUNK ? h + 1 : h;
 #pragma unroll
                     for (int u = 0; u < U; ++u) residual_load<SIDE>(p, hn, u, m0, wm, rr, col, ahead[u]);
+                    if (h == NCHUNK - 1) last_chunk();   // behind the look-ahead: loads it issues are the youngest, no wait of this loop covers them
 #pragma unroll
                     for (int u = 0; u < U; ++u) load8(stage + ((U + u) * RPS + rr) * LDW + cg * 8, in[u].v);
                     finish_multi<U, SIDE>(p, in, prm, h, U, m0, wm, wave, rr, cg, bcol, col, cb);
@@ -1413,7 +1417,47 @@ __global__ __launch_bounds__(256, 1) void gemm256w_bf16_kernel(const GemmParams 
 #ifdef ADCDIFF_STAMPS
     const long long rtb = __builtin_amdgcn_s_memrealtime();
 #endif
-    Epi::template run<true, EPI_U, SIDE>(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch);
+    // A workgroup's first two K tiles come from beyond L2 (the loop's prefetch starts at tile 2): issuing their LDS-DMA pieces
+    // takes 4.6 us at N = K = 2048 (rows 4 KB apart), against 1.3 us per tile in the loop.  So a workgroup touches, near the end of
+    // its epilogue, the lines that the first two K tiles of its successor on this XCD will read (workgroup blockIdx + pf_next, i.e.
+    // 1/8 of pf_next tiles further on: the same columns and the tile rows behind when the tiles per row divide that).  The ntn
+    // workgroups of a tile row split the A rows, the tile rows that share a column of W its rows; one dword per 128-byte line by
+    // LDS-DMA into a part of the main loop's LDS that the epilogue does not use (no register waits for the data, and the
+    // compiler, which does not see these loads, puts no wait in their way); lanes without a line point past the descriptor's
+    // range (no access).  Late in the epilogue, because its stores sweep the L2: touched at the start, the lines were gone again.
+    auto touch_successor = [&]() {
+        const int step = p.pf_next >> 3;   // tiles between a workgroup and its successor
+        if (step > 0 && (nwg & 7) == 0 && (int)blockIdx.x + p.pf_next < nwg && step % p.ntn == 0 && step / p.ntn <= 256 && p.ktiles[0] >= 2) {
+            const int R = step / p.ntn;                       // tile rows that share a column of W at a time
+            const int a_rows = 256 / p.ntn, w_rows = 256 / R;
+            const int mt = bid / p.ntn;
+            const unsigned lda_b = (unsigned)p.lda[0] * 2u, ldw_b = (unsigned)p.ldw * 2u;
+            auto make_srd = [](unsigned long long base, unsigned bytes) {
+                return i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)base), __builtin_amdgcn_readfirstlane((int)((unsigned)(base >> 32) & 0xffffu)),
+                             __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+            };
+            const i32x4 srd_a = make_srd((unsigned long long)p.A[0] + (unsigned long long)((long)(mt + R) * 256 + nidx * a_rows) * lda_b,
+                                         (unsigned)(a_rows - 1) * lda_b + 256u);
+            const i32x4 srd_w = make_srd((unsigned long long)p.W + (unsigned long long)((long)n0 + (mt % R) * w_rows) * ldw_b,
+                                         (unsigned)(w_rows - 1) * ldw_b + 256u);
+            const unsigned sink = lds0 + 98304u + (unsigned)wave * 256u;   // behind the epilogue's staging regions
+            int va[2], vw[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = tid + 256 * j;
+                va[j] = i < 2 * a_rows ? (int)((unsigned)(i >> 1) * lda_b + (unsigned)(i & 1) * 128u) : 0x7ffffff0;
+                vw[j] = i < 2 * w_rows ? (int)((unsigned)(i >> 1) * ldw_b + (unsigned)(i & 1) * 128u) : 0x7ffffff0;
+            }
+            int m0_keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\t"
+                         "buffer_load_dword %1, %5, 0 offen lds\n\tbuffer_load_dword %2, %5, 0 offen lds\n\t"
+                         "buffer_load_dword %3, %6, 0 offen lds\n\tbuffer_load_dword %4, %6, 0 offen lds\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(m0_keep) : "v"(va[0]), "v"(va[1]), "v"(vw[0]), "v"(vw[1]), "s"(srd_a), "s"(srd_w), "s"(sink));
+        }
+    };
+    Epi::template run<true, EPI_U, SIDE>(acc, p, m0, n0, wm, wn, wave, lane, reinterpret_cast<float*>(smem), prm, xch, touch_successor);
+    if constexpr (SIDE != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup's LDS is handed on
 #ifdef ADCDIFF_STAMPS
     const long long rt2 = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1472,6 +1516,17 @@ static int launch256(const GemmParams& p, bool pipelined, hipStream_t stream) {
     return check_launch("gemm256");
 }
 
+// CUs of the current device = workgroups of the four-wave kernel resident at a time (one per CU); 0 if the query fails
+static int compute_units() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v == 0 && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        cache[dev].store(v, std::memory_order_relaxed);
+    return v > 0 ? v : 0;
+}
+
 // SIDE (see Epilogue::rowbias_load): 0 serves every launch; 1 / 2 know at compile time that there is no per-row bias and no /
 // a residual (and no activation, schedule update or float32 output), which lets the epilogue fetch the residual one batch ahead
 template <int EPI_U, int SIDE = 0>
@@ -1482,6 +1537,7 @@ static int launch256w(const GemmParams& p, hipStream_t stream) {
     GemmParams q = p;
     q.ntn = p.N / 256;
     q.pf_w = (int)debug_value(DBG_GEMM_PF_W);
+    q.pf_next = debug_value(DBG_GEMM_PF_NEXT) ? compute_units() : 0;
     const int grid = (p.M / 256) * q.ntn;
 #ifdef ADCDIFF_STAMPS
     static long long* dbuf = nullptr;

@@ -356,6 +356,8 @@ int adcdiff_clip_adamw_step_noalloc(const adcdiff_opt_tensor* tensors, int n_ten
  *   gemm_ring (0), gemm_ring2 (1), gemm_ring_max (512), gemm_w4 (1), gemm_w4_min_n (512), gemm_w1 (1), gemm_w1_rows (1024),
  *   gemm_cl (1)          kernel-family switches of adcdiff_gemm's dispatch (gemm_w4_min_n: the narrowest layer the four-wave kernel takes)
  *   gemm_pf_w (1)        0 = the four-wave kernel prefetches only its A rows into L2, not the W rows
+ *   gemm_pf_next (1)     0 = the four-wave kernel does not touch, near the end of its epilogue, the operand lines that the first two
+ *                        K tiles of its successor workgroup on the same XCD will read
  *   gemm_splitk (1)      0 = never the few-row kernel that splits K over workgroups (splitk_scratch is ignored): small batches are
  *                        then bit-identical to large ones
  *   step_fold (1)        0 = the reverse step and encoder.0's GroupNorm as launches of their own in the sampling loops
