@@ -152,7 +152,10 @@ def phase(s, read_stage, read_half, issue_stage, end):
         i = x >> 3
         j = 7 - (x & 7) if (i & 1) else (x & 7)
         mfma(i, j, s)
-        if read_stage is not None and (x & 1) and x < 32:
+        if read_stage is not None and "readlate" in ABLATE:
+            if (x & 1) and x >= 32:
+                read_frag((x - 32) >> 1, s ^ 1)
+        elif read_stage is not None and (x & 1) and x < 32:
             read_frag(x >> 1, s ^ 1)
         if issue_stage is not None:
             if first_half:
@@ -340,6 +343,8 @@ def main():
             f.write("// Generated by gen_w4_mainloop.py --stamps -- do not edit.\n")
             emit(f, "ADCDIFF_W4S_MAINLOOP_ASM")
         return
+    import os
+    ABLATE.update(x for x in os.environ.get("W4_ABLATE", "").split("+") if x)   # experiments: W4_ABLATE=dmafirsthalf+readlate
     generate()
     out = sys.argv[1] if len(sys.argv) > 1 else "w4_mainloop.inc"
     with open(out, "w") as f:
