@@ -388,6 +388,7 @@ const DebugEntry kDebug[DBG_NKEYS] = {
     {"gemm_ring_max", 512},   // launches with at most this many 128-row workgroups take a ring of LDS stages
     {"gemm_w4", 1},           // 0: the eight-wave kernel instead of the four-wave 256-tile kernel
     {"gemm_w4_min_n", 512},   // the narrowest layer (output columns) the four-wave kernel takes
+    {"gemm_big_min_k", 256},  // the shortest K for which the four-wave kernel is taken by default (512: the rule before)
     {"gemm_w1", 1},           // 0: the tile kernels instead of the one-wave kernels for few live rows
     {"gemm_w1_rows", 1024},   // live rows up to which the one-wave kernels are taken
     {"gemm_cl", 1},           // 0: never the loader-wave variant of the one-wave kernel

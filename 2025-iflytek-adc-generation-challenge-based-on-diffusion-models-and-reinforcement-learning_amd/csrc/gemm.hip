@@ -2320,7 +2320,10 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     if (a.dtype == ADCDIFF_BF16 && a.M % 256 == 0 && a.N % 256 == 0 && a.tile_hint != 128) {
         const int forced = (int)debug_value(DBG_GEMM_TILE);
         const bool enough_tiles = forced != 128 && (long)(a.M / 256) * (a.N / 256) * p.ksplit >= 192;
-        const bool long_k = kslice >= 512;
+        // K = 256 (four K tiles) pays on the four-wave kernel unless the epilogue carries the schedule update: 69 -> 54 us for the
+        // N = 512 layer at M = 65536, but 150 -> 167 us for the output head with the update folded in
+        const bool long_k = kslice >= 512 || (kslice >= (int)debug_value(DBG_GEMM_BIG_MIN_K) && a.update.kind == 0 &&
+                                              a.N >= (int)debug_value(DBG_GEMM_W4_MIN_N));
         big = forced == 256 || forced == 2561 || a.tile_hint == 256 || a.tile_hint == 2561 || a.tile_hint == 2560 || (a.tile_hint >= 2564 && a.tile_hint <= 2568) || (enough_tiles && long_k);
         pipelined = a.tile_hint == 2561 || (a.tile_hint != 2560 && pipe_default);
     }

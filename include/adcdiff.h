@@ -353,7 +353,7 @@ int adcdiff_clip_adamw_step_noalloc(const adcdiff_opt_tensor* tensors, int n_ten
  *                        rows, 2567 the same without the epilogue variants specialised on the launch's side inputs); 1 / 3 the 128-row kernel with one LDS stage / the three-stage ring; 32 the one-wave kernel,
  *                        325 its variant with loader waves, 327 the split-K variant (needs splitk_scratch)
  *   gemm_tile (0)        128 / 256 / 2561: as the hint of that value, for every bf16 launch
- *   gemm_ring (0), gemm_ring2 (1), gemm_ring_max (512), gemm_w4 (1), gemm_w4_min_n (512), gemm_w1 (1), gemm_w1_rows (1024),
+ *   gemm_ring (0), gemm_ring2 (1), gemm_ring_max (512), gemm_w4 (1), gemm_w4_min_n (512), gemm_big_min_k (256), gemm_w1 (1), gemm_w1_rows (1024),
  *   gemm_cl (1)          kernel-family switches of adcdiff_gemm's dispatch (gemm_w4_min_n: the narrowest layer the four-wave kernel takes)
  *   gemm_pf_w (1)        0 = the four-wave kernel prefetches only its A rows into L2, not the W rows
  *   gemm_pf_next (1)     0 = the four-wave kernel does not touch, near the end of its epilogue, the operand lines that the first two
