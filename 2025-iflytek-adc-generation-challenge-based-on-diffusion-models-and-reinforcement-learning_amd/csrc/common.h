@@ -22,7 +22,7 @@ int fail(int code, const char* fmt, ...);
 // Measurement switches behind adcdiff_debug_set (include/adcdiff.h): every default is the shipped behaviour, and with no
 // adcdiff_debug_set call the kernel choice is a function of the arguments alone.  No environment variable is read.
 enum DebugKey { DBG_TILE_HINTS, DBG_GEMM_TILE, DBG_GEMM_RING, DBG_GEMM_RING2, DBG_GEMM_RING_MAX, DBG_GEMM_W4, DBG_GEMM_W4_MIN_N, DBG_GEMM_BIG_MIN_K, DBG_GEMM_W1, DBG_GEMM_W1_ROWS,
-                DBG_GEMM_CL, DBG_GEMM_SPLITK, DBG_GEMM_PF_W, DBG_GEMM_PF_NEXT, DBG_STEP_FOLD, DBG_TRAIN_TRANSPOSE, DBG_TRAIN_GROUP_DW, DBG_TRAIN_FUSE_CAST, DBG_SYNC, DBG_NKEYS };
+                DBG_GEMM_CL, DBG_GEMM_SPLITK, DBG_GEMM_PF_W, DBG_GEMM_PF_NEXT, DBG_STEP_FOLD, DBG_TRAIN_TRANSPOSE, DBG_TRAIN_GROUP_DW, DBG_TRAIN_FUSE_CAST, DBG_TRAIN_FUSED_FWD, DBG_SYNC, DBG_NKEYS };
 long long debug_value(int key);
 
 inline hipStream_t as_stream(adcdiff_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

@@ -399,6 +399,7 @@ const DebugEntry kDebug[DBG_NKEYS] = {
     {"train_transpose", 0},   // 1: backward products on transposed copies (the NT kernel) instead of gemm_tr
     {"train_group_dw", 1},    // 0: every weight-gradient product of the backward pass as a launch of its own
     {"train_fuse_cast", 1},   // 0: bf16 copies and bias column sums of the backward pass by cast launches of their own
+    {"train_fused_fwd", 1},   // 0: the training forward with every GroupNorm as a launch of its own
     {"sync", 0},              // 1: synchronise and check after every training launch
 };
 std::atomic<long long> g_debug[DBG_NKEYS];

@@ -530,8 +530,16 @@ using namespace adcdiff;
 static size_t train_forward_bytes(adcdiff_unet* n, int B) {
     Bump ws(nullptr, 0);
     cond_embed_taped(n, nullptr, 0, B, ws, true, nullptr, nullptr);   // sized for the conditional case, the larger one
+    const size_t base = ws.off;
     forward_unfused(n, nullptr, 0, B, nullptr, 0, nullptr, 0, nullptr, 0, ws, true, nullptr);
-    return ws.off;
+    size_t need = ws.off;
+    if (n->fused) {   // either forward may run (debug switch train_fused_fwd): size for the larger carving
+        Bump w2(nullptr, 0);
+        w2.off = base;
+        forward_taped(n, nullptr, 0, B, nullptr, nullptr, 0, nullptr, 0, w2, true, nullptr, nullptr, 0.0f, 0);
+        if (w2.off > need) need = w2.off;
+    }
+    return need;
 }
 
 static int backward_impl(adcdiff_unet* n, const float* d_eps, int lde, const adcdiff_unet_grads* gr, int B, Bump& ws, bool dry, hipStream_t st);
@@ -567,6 +575,8 @@ extern "C" int adcdiff_unet_train_forward(adcdiff_unet* n, const float* x, int l
     n->tape = Tape{};
     if (cond) TRY(cond_embed_taped(n, cond, ldc, B, ws, false, as_stream(stream_), &n->tape));
     else cond_embed_taped(n, nullptr, 0, B, ws, true, nullptr, nullptr);   // the same carving with and without a condition
+    if (n->fused && debug_value(DBG_TRAIN_FUSED_FWD) != 0)
+        return forward_taped(n, x, ldx, B, t_rows, n->tape.cemb, n->H, eps, lde, ws, false, as_stream(stream_), &n->tape, dropout_p, dropout_seed);
     return forward_unfused(n, x, ldx, B, t_rows, 0, n->tape.cemb, n->H, eps, lde, ws, false, as_stream(stream_), &n->tape, dropout_p, dropout_seed);
 }
 

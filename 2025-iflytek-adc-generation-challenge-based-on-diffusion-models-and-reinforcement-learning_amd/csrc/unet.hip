@@ -320,6 +320,120 @@ int adcdiff::forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, co
     return ADCDIFF_OK;
 }
 
+// The training forward where every GroupNorm can run in a GEMM epilogue (n->fused): the same tape as forward_unfused -- float32 h1
+// and o per block, the operand-typed a1 / a2 / block inputs -- with norm1 of the next block, the consuming decoder's norm1 slice of
+// a skip tensor and output_norm applied by the producing block's second GEMM (written straight into the concatenated a1 of the
+// consumer), and norm2 by the first GEMM when there is no dropout.  One stand-alone GroupNorm (the latent's) plus ten with
+// dropout, instead of 25.  The statistics come from the float32 accumulators that out_f32 stores, so the backward pass, which
+// recomputes them from the tape, sees the same inputs (diffusion_model.py:875-907).
+int adcdiff::forward_taped(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, const float* cemb, int ldce,
+                           float* eps, int lde, Bump& ws, bool dry, hipStream_t st, Tape* tape, float drop_p, uint64_t drop_seed) {
+    const int Bp = (int)round_up((size_t)B, 128);
+    const size_t e = (size_t)n->esz;
+    const int H = n->H, dt = n->dtype;
+    const adcdiff_unet_params& p = n->prm;
+    const bool cond = cemb != nullptr;
+    const bool f32 = dt == ADCDIFF_F32;
+
+    const void* s_op = nullptr;
+    if (cond || dry) {   // the dry run sizes for the conditional case, the larger one
+        void* s = ws.take((size_t)Bp * H * e);
+        if (!dry) TRY(temb_silu(n->te_table, H, n->T, t_rows, 0, cemb, ldce, dt, s, H, B, H, st));
+        s_op = s;
+    }
+    // every block's first operand a1 = SiLU(GroupNorm1(cat(inputs))), [Bp, cin], and the output head's
+    char* a1[10];
+    for (int i = 0; i < 10; ++i) a1[i] = (char*)ws.take((size_t)Bp * n->blk[i].cin * e);
+    void* a_out = ws.take((size_t)Bp * H * e);
+    void* x_raw = ws.take((size_t)Bp * n->D * e);
+    if (!dry) TRY(groupnorm_silu(x, ldx, B, n->D, n->blk[0].g1, p.blocks[0].norm1_w, p.blocks[0].norm1_b, 1e-5f, dt, a1[0], n->D, x_raw, n->D, st));
+
+    const float* o_f32[10];
+    const void* o_raw[10];
+    for (int i = 0; i < 10; ++i) {
+        const BlockPlan& b = n->blk[i];
+        const adcdiff_block_params& q = p.blocks[i];
+        // the block's input parts: the previous output (the latent for encoder.0) and, in the decoder, the skip
+        const float* in_f32[2] = {i == 0 ? x : o_f32[i - 1], i >= 6 ? o_f32[9 - i] : nullptr};
+        const int in_ld[2] = {i == 0 ? ldx : n->blk[i - 1].cout, i >= 6 ? n->blk[9 - i].cout : 0};
+        const void* in_raw[2] = {i == 0 ? x_raw : o_raw[i - 1], i >= 6 ? o_raw[9 - i] : nullptr};
+        const int nparts = i >= 6 ? 2 : 1;
+        BlockTape* bt = tape ? &tape->blk[i] : nullptr;
+        if (bt) {
+            for (int k = 0; k < nparts; ++k) { bt->in_f32[k] = in_f32[k]; bt->in_ld[k] = in_ld[k]; bt->in_c[k] = b.part_c[k]; bt->in_raw[k] = in_raw[k]; }
+            bt->nparts = nparts; bt->a1 = a1[i];
+        }
+        // h1 = linear1(a1) + time_proj(SiLU(t_emb)); without dropout the epilogue also writes a2 = SiLU(GroupNorm2(h1))
+        float* h1 = (float*)ws.take((size_t)Bp * b.cout * 4);
+        void* a2 = ws.take((size_t)Bp * b.cout * e);
+        if (!dry) {
+            adcdiff_gemm_args g = gemm_args(dt, Bp, B, b.cout);
+            g.nseg = 1; g.A[0] = a1[i]; g.lda[0] = b.cin; g.K[0] = b.cin;
+            g.W = b.w1cat; g.ldw = b.ldw1;
+            if (cond) {
+                g.nseg = 2; g.A[1] = s_op; g.lda[1] = H; g.K[1] = H;
+                g.bias = b.bias1_cond;
+            } else {
+                g.bias = b.bias1;
+                g.rowbias = n->tb_table + b.tb_off; g.ldrb = n->sumN; g.rowbias_idx = t_rows; g.rowbias_rows = n->T;
+            }
+            g.out_f32 = h1; g.ldo_f32 = b.cout;
+            if (drop_p <= 0.0f) {
+                g.n_gn = 1; g.gn_eps = 1e-5f;
+                g.gn[0] = adcdiff_gn_out{q.norm2_w, q.norm2_b, a2, b.cout, b.gs2};
+            }
+            TRY(gemm_dispatch(g, st));
+            // the dropout of diffusion_model.py:898 (counter RNG keyed by layer and row) stays with the stand-alone kernel
+            if (drop_p > 0.0f) TRY(groupnorm_silu(h1, b.cout, B, b.cout, b.g2, q.norm2_w, q.norm2_b, 1e-5f, dt, a2, b.cout, nullptr, 0, st, drop_p, drop_seed, (uint32_t)i));
+        }
+        if (bt) { bt->h1 = h1; bt->a2 = a2; }
+        // o = linear2(a2) + residual_proj(input), normalised for its consumers on the way out
+        float* o = (float*)ws.take((size_t)Bp * b.cout * 4);
+        void* raw = (!f32 && i < 9) ? ws.take((size_t)Bp * b.cout * e) : nullptr;   // in float32 o is its own operand
+        if (!dry) {
+            adcdiff_gemm_args g = gemm_args(dt, Bp, B, b.cout);
+            g.nseg = 1; g.A[0] = a2; g.lda[0] = b.cout; g.K[0] = b.cout;
+            g.W = b.w2cat; g.ldw = b.ldw2; g.bias = b.bias2;
+            if (b.has_res) {
+                for (int k = 0; k < nparts; ++k) { g.A[g.nseg] = in_raw[k]; g.lda[g.nseg] = b.part_c[k]; g.K[g.nseg] = b.part_c[k]; ++g.nseg; }
+            } else {
+                g.residual = in_raw[0]; g.ldr = b.part_c[0];
+            }
+            g.out_f32 = o; g.ldo_f32 = b.cout;
+            if (raw) { g.out_op = raw; g.ldo_op = b.cout; }
+            g.gn_eps = 1e-5f;
+            if (i < 9) {
+                const BlockPlan& nb = n->blk[i + 1];
+                g.gn[g.n_gn++] = adcdiff_gn_out{p.blocks[i + 1].norm1_w, p.blocks[i + 1].norm1_b, a1[i + 1], nb.cin, nb.gs1};
+            } else {
+                g.gn[g.n_gn++] = adcdiff_gn_out{p.out_norm_w, p.out_norm_b, a_out, H, H / num_groups(H)};
+            }
+            if (i <= 3) {   // decoder 9 - i reads this output as the second half of its input (diffusion_model.py:781-782)
+                const BlockPlan& db = n->blk[9 - i];
+                g.gn[g.n_gn++] = adcdiff_gn_out{p.blocks[9 - i].norm1_w + db.part_c[0], p.blocks[9 - i].norm1_b + db.part_c[0],
+                                                a1[9 - i] + (size_t)db.part_c[0] * e, db.cin, db.gs1};
+            }
+            TRY(gemm_dispatch(g, st));
+        }
+        if (bt) bt->o = o;
+        o_f32[i] = o;
+        o_raw[i] = f32 ? (const void*)o : raw;
+    }
+    if (tape) {
+        tape->a_out = a_out; tape->B = B; tape->t_rows = t_rows; tape->drop_p = drop_p; tape->drop_seed = drop_seed;
+        tape->s_op = cond ? s_op : nullptr;
+        tape->valid = !dry;
+    }
+    if (!dry) {   // output head (diffusion_model.py:786-788): its GroupNorm + SiLU was applied by decoder.3's second GEMM
+        adcdiff_gemm_args g = gemm_args(dt, Bp, B, n->O);
+        g.nseg = 1; g.A[0] = a_out; g.lda[0] = H; g.K[0] = H; g.W = n->w_out; g.ldw = H; g.bias = p.out_b;
+        g.out_f32 = eps; g.ldo_f32 = lde;
+        TRY(gemm_dispatch(g, st));
+    }
+    if (tape) tape->ws_used = ws.off;
+    return ADCDIFF_OK;
+}
+
 namespace {
 
 // The fused path (see the header comment).  Activations are kept only in the operand type.

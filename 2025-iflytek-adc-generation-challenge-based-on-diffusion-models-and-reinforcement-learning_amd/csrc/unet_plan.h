@@ -72,7 +72,7 @@ struct BlockPlan {
     int gs1, gs2;   // channels per GroupNorm group of norm1 (over the whole concatenated input) and norm2
 };
 
-// What the unfused forward leaves in the workspace for the backward pass (pointers into the caller's workspace).
+// What a training forward leaves in the workspace for the backward pass (pointers into the caller's workspace).
 struct BlockTape {
     const float* in_f32[2];   // block input part(s), float32 [rows, C] (leading dimension in_ld)
     int in_ld[2], in_c[2], nparts;
@@ -132,6 +132,8 @@ int plan_dims(adcdiff_unet* n, int input_dim, int hidden_dim, int output_dim, in
 int forward_unfused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, int t_uniform, const float* cemb,
                     int ldce, float* eps, int lde, Bump& ws, bool dry, hipStream_t st, Tape* tape = nullptr, float drop_p = 0.0f,
                     uint64_t drop_seed = 0);
+int forward_taped(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t* t_rows, const float* cemb, int ldce, float* eps,
+                  int lde, Bump& ws, bool dry, hipStream_t st, Tape* tape, float drop_p, uint64_t drop_seed);
 adcdiff_gemm_args gemm_args(int dtype, int M, int m_valid, int N);
 }  // namespace adcdiff
 

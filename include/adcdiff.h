@@ -366,6 +366,8 @@ int adcdiff_clip_adamw_step_noalloc(const adcdiff_opt_tensor* tensors, int n_ten
  *                        partial sums) instead of one grouped launch at the end of the pass
  *   train_fuse_cast (1)  0 = the bf16 operand copies and bias gradients of adcdiff_unet_backward by cast launches of their own instead
  *                        of the GroupNorm backward kernel that finishes the tensor
+ *   train_fused_fwd (1)  0 = adcdiff_unet_train_forward with every GroupNorm as a launch of its own instead of in the epilogue of the
+ *                        GEMM that produces its input (only norm2 with dropout and the latent's norm1 are stand-alone launches)
  *   sync (0)             1 = synchronise after every launch of adcdiff_unet_backward and name the first that fails
  * Values are process-wide and read by every later call; unknown keys are rejected. */
 int adcdiff_debug_set(const char* key, long long value);

@@ -207,6 +207,50 @@ def test_backward_without_transposed_copies_gives_the_same_gradients(dims, B, co
     assert exact >= 25
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+@pytest.mark.parametrize("dtype,dims,B", [("fp32", (128, 128, 128), 40), ("bf16", (128, 128, 128), 64), ("bf16", (512, 256, 512), 1024)])
+def test_training_forward_with_groupnorm_in_the_gemm_epilogues_matches_the_stand_alone_kernels(dtype, dims, B, dropout):
+    """The training forward applies norm1 of the next block, a skip's norm1 slice, output_norm and (without dropout) norm2 in the
+    epilogue of the GEMM that produces their input; debug switch train_fused_fwd = 0 runs every GroupNorm as a launch of its own
+    (the path the golden gradients were first pinned on).  Same tape, same backward: loss and gradients agree to the float32
+    summation order of the group statistics (a last bf16 place of an activation here and there in bf16)."""
+    cfg = dict(input_dim=dims[0], hidden_dim=dims[1], output_dim=dims[2], compute_dtype=dtype, max_batch_size=4096)
+    m = adcdiff.DiffusionModel(cfg)
+    for mod in m.model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = dropout
+    m.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(1234, *dims).items()})
+    m.model.train()
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(B, dims[0], generator=gen).cuda()
+    nz = torch.randn(B, dims[0], generator=gen).cuda()
+    t = torch.randint(0, 1000, (B,), generator=gen).cuda()
+
+    def run(fused):
+        adcdiff._lib.debug_set("train_fused_fwd", 1 if fused else 0)
+        m.model.zero_grad(set_to_none=True)
+        torch.manual_seed(3)             # the dropout seed is drawn from torch: same masks in both passes
+        loss = m.p_losses(x, t, None, noise=nz)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.clone() for k, p in m.model.named_parameters() if p.grad is not None}
+
+    try:
+        (l1, g1), (l0, g0) = run(True), run(False)
+    finally:
+        adcdiff._lib.debug_set("train_fused_fwd", 1)
+    ltol, gtol = (1e-6, 2e-4) if dtype == "fp32" else (2e-3, 3e-2)
+    assert abs(l1 - l0) <= ltol * abs(l0), (l1, l0)
+    assert g1.keys() == g0.keys() and len(g0) >= 100
+    worst = 0.0
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        err = float((g1[k] - g0[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-6)
+        worst = max(worst, err)
+        assert err <= gtol, (k, err)
+    print("fused training forward: loss %.6f / %.6f, worst gradient difference %.2e of the tensor's scale" % (l1, l0, worst))
+
+
 @pytest.mark.parametrize("opt_cls", ["AdamW", "Adam"])
 def test_fused_clip_adamw_matches_torch(opt_cls):
     """clip_grad_norm_(1.0) + optimizer.step() of torch against the three-launch version on the same tensors: ragged sizes
