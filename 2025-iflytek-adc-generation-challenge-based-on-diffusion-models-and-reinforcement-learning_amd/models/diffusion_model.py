@@ -565,7 +565,10 @@ class DiffusionModel(nn.Module):
                                         total_steps=config.get('total_steps', 10000))
         else:
             self.scheduler = CosineAnnealingLR(self.optimizer, T_max=config.get('max_epochs', 100))
-        self.scaler = None   # bfloat16 needs no loss scaling; kept as an attribute of the reference's surface
+        # diffusion_model.py:87 holds a GradScaler when use_mixed_precision is set.  bfloat16 operands with float32 accumulation and
+        # float32 master weights need no loss scaling, so the attribute is a DISABLED scaler: scale() returns its argument, step()
+        # calls optimizer.step(), unscale_() and update() do nothing -- code written against the reference's attribute keeps working.
+        self.scaler = torch.amp.GradScaler("cuda", enabled=False) if self.use_mixed_precision else None
 
         self.memory_threshold = config.get('memory_threshold', 0.85)
         self.gc_frequency = config.get('gc_frequency', 50)

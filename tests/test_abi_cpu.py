@@ -45,6 +45,12 @@ def test_mirror_keeps_reference_surface(golden_a, golden_tiny):
     for attr in ("input_dim", "hidden_dim", "output_dim", "num_timesteps", "device", "max_batch_size", "beta_schedule", "alpha",
                  "alpha_cumprod", "alpha_cumprod_prev", "optimizer", "scheduler", "scaler"):
         assert hasattr(m, attr), attr
+    # the reference holds a GradScaler under use_mixed_precision (its default) and None otherwise (diffusion_model.py:87); here the
+    # scaler is a disabled one (bf16 needs no loss scaling): the calls the reference's train_step makes on it are pass-throughs
+    assert m.scaler is not None and not m.scaler.is_enabled()
+    probe = torch.ones(1, requires_grad=True)
+    assert m.scaler.scale(probe) is probe
+    assert adcdiff.DiffusionModel(dict(cfg, use_mixed_precision=False)).scaler is None
     for meth in ("q_sample", "p_losses", "p_sample", "p_sample_loop", "sample", "ddim_sample_loop", "ddim_step", "train_step",
                  "save_model", "load_model", "cleanup_resources", "_extract", "_posterior_variance", "_make_ddim_timesteps"):
         assert callable(getattr(m, meth)), meth
