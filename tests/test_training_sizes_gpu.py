@@ -35,10 +35,13 @@ GATES = {
 
 # conditional loss p_losses(x, t, condition): loss, worst grad_rel over 12 tensors (condition_embed.{0,2}, time_embed, time_proj and
 # others), global norm.  Measured: fp32 0 / 1e-7 / 1e-7, 2.2e-5 / 6.0e-6 / 7.9e-5, 5e-7 / 2e-7 / 2.4e-5;
-# bf16 2.3e-4 / 1.3e-5 / 1.9e-4, 0.10 / 0.018 / 0.31, 1.5e-3 / 4.5e-4 / 6.4e-2
+# bf16 2.3e-4 / 1.3e-5 / 1.9e-4, 0.10 / 0.018 / 0.31, 1.5e-3 / 4.5e-4 / 6.4e-2 with every GroupNorm as a launch of its own; with the
+# GroupNorms in the GEMM epilogues (the default since) 3.0e-4 / 3.4e-5 / 1.8e-4, 0.105 / 0.021 / 0.31, 9.7e-3 / 4.3e-4 / 6.4e-2: the
+# 128-wide model's groups of 4 channels at batch 8 turn the statistics' summation order into last-place flips of bf16 activations, and
+# its global norm moves by a percent with them (float32 agrees to 6e-7 on both paths)
 COND_GATES = {
     ("tiny_cond", "fp32"): (1e-6, 7e-5, 4e-6), ("train_a", "fp32"): (1e-6, 2e-5, 1e-6), ("train_b", "fp32"): (1e-6, 2.5e-4, 7e-5),
-    ("tiny_cond", "bf16"): (1e-3, 0.3, 5e-3), ("train_a", "bf16"): (2e-4, 6e-2, 1.5e-3), ("train_b", "bf16"): (6e-4, 0.9, 0.19),
+    ("tiny_cond", "bf16"): (1e-3, 0.3, 3e-2), ("train_a", "bf16"): (2e-4, 6e-2, 1.5e-3), ("train_b", "bf16"): (6e-4, 0.9, 0.19),
 }
 
 
