@@ -25,6 +25,31 @@ enum DebugKey { DBG_TILE_HINTS, DBG_GEMM_TILE, DBG_GEMM_RING, DBG_GEMM_RING2, DB
                 DBG_GEMM_CL, DBG_GEMM_SPLITK, DBG_GEMM_PF_W, DBG_GEMM_PF_NEXT, DBG_STEP_FOLD, DBG_TRAIN_TRANSPOSE, DBG_TRAIN_GROUP_DW, DBG_TRAIN_FUSE_CAST, DBG_TRAIN_FUSED_FWD, DBG_SYNC, DBG_NKEYS };
 long long debug_value(int key);
 
+// Sum over aligned groups of LPG adjacent lanes, every lane receiving its group's sum: the xor butterfly (partner lane ^ 1, ^ 2,
+// ^ 4, ...) on the cross-lane data path instead of ds_bpermute.  From the third step on every lane of a half already holds the same
+// partial sum, so the mirror patterns (lane ^ 7 within 8, lane ^ 15 within 16) deliver the same addend as lane ^ 4 / lane ^ 8:
+// the result equals the __shfl_xor loop's bit for bit.  LPG = 0: the loop, for a count known only at run time.
+#ifdef __HIPCC__
+template <int CTRL>
+__device__ __forceinline__ float lane_dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int LPG>
+__device__ __forceinline__ float lanes_allsum(float x, int lanes_runtime) {
+    if constexpr (LPG == 0) {
+        for (int m = 1; m < lanes_runtime; m <<= 1) x += __shfl_xor(x, m);
+    } else {
+        if constexpr (LPG >= 2) x += lane_dpp<0xB1>(x);    // quad_perm [1,0,3,2]
+        if constexpr (LPG >= 4) x += lane_dpp<0x4E>(x);    // quad_perm [2,3,0,1]
+        if constexpr (LPG >= 8) x += lane_dpp<0x141>(x);   // row_half_mirror
+        if constexpr (LPG >= 16) x += lane_dpp<0x140>(x);  // row_mirror
+        if constexpr (LPG >= 32) x += __shfl_xor(x, 16);
+        if constexpr (LPG >= 64) x += __shfl_xor(x, 32);
+    }
+    return x;
+}
+#endif
+
 inline hipStream_t as_stream(adcdiff_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int check_launch(const char* what) {

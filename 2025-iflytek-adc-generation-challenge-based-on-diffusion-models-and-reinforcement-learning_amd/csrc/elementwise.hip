@@ -53,7 +53,7 @@ TimingScope::~TimingScope() {}
 // One float4 (four channels) per thread; a group of gs channels spans gs/4 adjacent lanes, so the two
 // statistics passes (mean, then centred sum of squares) are xor-shuffle reductions over gs/4 lanes.
 // Reads x once, fully coalesced; writes the activation (and optionally a converted copy of x).
-template <typename OutT>
+template <typename OutT, int LPG>
 __global__ __launch_bounds__(256) void gn_silu_vec_kernel(const float* __restrict__ x, int ldx, long total4, int c4,
                                                           int lanes_per_group, float inv_gs, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, OutT* __restrict__ out,
@@ -65,12 +65,10 @@ __global__ __launch_bounds__(256) void gn_silu_vec_kernel(const float* __restric
     const long row = ee / c4;
     const int col = (int)(ee - row * c4) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + col);
-    float s = (v[0] + v[1]) + (v[2] + v[3]);
-    for (int m = 1; m < lanes_per_group; m <<= 1) s += __shfl_xor(s, m);
+    const float s = lanes_allsum<LPG>((v[0] + v[1]) + (v[2] + v[3]), lanes_per_group);
     const float mean = s * inv_gs;
     const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
-    float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
-    for (int m = 1; m < lanes_per_group; m <<= 1) q += __shfl_xor(q, m);
+    const float q = lanes_allsum<LPG>((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]), lanes_per_group);
     const float rstd = 1.0f / __builtin_sqrtf(q * inv_gs + eps);
     if (!live) return;
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
@@ -131,8 +129,20 @@ static int gn_launch(const float* x, int ldx, int M, int C, int groups, const fl
     if (vec) {
         const long total4 = (long)M * (C / 4);
         const long blocks = (total4 + 255) / 256;
-        hipLaunchKernelGGL((gn_silu_vec_kernel<OutT>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, total4, C / 4, gs / 4,
-                           1.0f / (float)gs, gamma, beta, eps, out, ldo, raw, ldraw, drop_p, drop_seed, drop_layer);
+        // the group size as a template argument: the group sums then run on the cross-lane data path (same bits)
+#define ADCDIFF_GN_VEC(LPG)                                                                                                          \
+    hipLaunchKernelGGL((gn_silu_vec_kernel<OutT, LPG>), dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, total4, C / 4, gs / 4, \
+                       1.0f / (float)gs, gamma, beta, eps, out, ldo, raw, ldraw, drop_p, drop_seed, drop_layer)
+        switch (gs / 4) {
+            case 1: ADCDIFF_GN_VEC(1); break;
+            case 2: ADCDIFF_GN_VEC(2); break;
+            case 4: ADCDIFF_GN_VEC(4); break;
+            case 8: ADCDIFF_GN_VEC(8); break;
+            case 16: ADCDIFF_GN_VEC(16); break;
+            case 32: ADCDIFF_GN_VEC(32); break;
+            default: ADCDIFF_GN_VEC(64); break;
+        }
+#undef ADCDIFF_GN_VEC
     } else {
         if (drop_p > 0.0f) return fail(ADCDIFF_E_BADARG, "groupnorm_silu: dropout needs group sizes that are powers of two >= 4");
         const long total = (long)M * groups;

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const InT* __restri
 // dst = (accumulate ? dst : 0) + d_u + add.
 // A workgroup is c4t = min(C / 4, 256) column lanes x 256 / c4t row lanes (no idle lanes for narrow layers); the host picks
 // rpt (8..32) so that the grid has enough workgroups; rows are taken two at a time so that four loads are in flight.
+template <int LPG>
 __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* __restrict__ u, long ldu, const float* __restrict__ dA, long ldda,
                                                           int rows, int c4t, int rpt, int lanes_per_group, float inv_gs,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -87,12 +88,10 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* __restric
         for (int k = 0; k < 2; ++k) {
             const int r = rr[k];
             const f32x4 x = xs[k], da = das[k];
-            float s = (x[0] + x[1]) + (x[2] + x[3]);
-            for (int m = 1; m < lanes_per_group; m <<= 1) s += __shfl_xor(s, m);
+            const float s = lanes_allsum<LPG>((x[0] + x[1]) + (x[2] + x[3]), lanes_per_group);
             const float mean = s * inv_gs;
             const f32x4 d = {x[0] - mean, x[1] - mean, x[2] - mean, x[3] - mean};
-            float v = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
-            for (int m = 1; m < lanes_per_group; m <<= 1) v += __shfl_xor(v, m);
+            const float v = lanes_allsum<LPG>((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]), lanes_per_group);
             const float rstd = 1.0f / __builtin_sqrtf(v * inv_gs + eps);
             f32x4 keep = {1.0f, 1.0f, 1.0f, 1.0f};
             if (drop_p > 0.0f) keep = dropout_keep4(drop_seed, drop_layer, (uint64_t)r, (uint32_t)((drop_col0 + col) >> 2), drop_p);
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* __restric
                 s1 += dxh[i];
                 s2 += dxh[i] * xh[i];
             }
-            for (int m = 1; m < lanes_per_group; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+            s1 = lanes_allsum<LPG>(s1, lanes_per_group); s2 = lanes_allsum<LPG>(s2, lanes_per_group);
             s1 *= inv_gs; s2 *= inv_gs;
             if (count) {
                 f32x4 o;
@@ -369,9 +368,21 @@ static int gn_silu_bwd(const float* u, long ldu, const float* dA, long ldda, int
     if (cq.parts.off > cq.parts.cap || cq.n >= COLSUM_MAX_ITEMS) return fail(ADCDIFF_E_WORKSPACE, "unet_backward: internal sizing error (GroupNorm partial rows)");
     TimingScope ts(ADCDIFF_KIND_OTHER, rows, C, 0, 0.0, (double)rows * C * (12.0 + (dst_op ? 2.0 : 0.0)), st);
     const dim3 grid((unsigned)(c4 / g.c4t), (unsigned)g.nby);
-    hipLaunchKernelGGL(gn_silu_bwd_kernel, grid, dim3(256), 0, st, u, ldu, dA, ldda, rows, g.c4t, g.rpt, gs / 4, 1.0f / (float)gs, gamma, beta, 1e-5f,
-                       drop_p, drop_seed, drop_layer, drop_col0, add, ldadd, dst, lddst, accumulate, part, (long)3 * C,
-                       reinterpret_cast<bf16_t*>(dst_op), lddo, bias0 ? 1 : 0);
+    // the group size as a template argument: the four group sums per row then run on the cross-lane data path (same bits)
+#define ADCDIFF_GN_BWD(LPG)                                                                                                                 \
+    hipLaunchKernelGGL(gn_silu_bwd_kernel<LPG>, grid, dim3(256), 0, st, u, ldu, dA, ldda, rows, g.c4t, g.rpt, gs / 4, 1.0f / (float)gs, gamma, \
+                       beta, 1e-5f, drop_p, drop_seed, drop_layer, drop_col0, add, ldadd, dst, lddst, accumulate, part, (long)3 * C,          \
+                       reinterpret_cast<bf16_t*>(dst_op), lddo, bias0 ? 1 : 0)
+    switch (gs / 4) {
+        case 1: ADCDIFF_GN_BWD(1); break;
+        case 2: ADCDIFF_GN_BWD(2); break;
+        case 4: ADCDIFF_GN_BWD(4); break;
+        case 8: ADCDIFF_GN_BWD(8); break;
+        case 16: ADCDIFF_GN_BWD(16); break;
+        case 32: ADCDIFF_GN_BWD(32); break;
+        default: ADCDIFF_GN_BWD(64); break;
+    }
+#undef ADCDIFF_GN_BWD
     ColsumItem& it = cq.items[cq.n++];
     it.part = part; it.stride = (long)3 * C; it.nrows = g.nby; it.C = C;
     it.dst[0][0] = dgamma; it.dst[0][1] = nullptr; it.dst[1][0] = dbeta; it.dst[1][1] = nullptr; it.dst[2][0] = bias0; it.dst[2][1] = bias1;
