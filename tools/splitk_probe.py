@@ -7,6 +7,8 @@ import adcdiff
 from adcdiff import ops
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+for kv in sys.argv[3:]:   # debug switches of the library, key=value
+    adcdiff._lib.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
 bf = torch.bfloat16
 DEV = "cuda"
 # (K segments, N, GroupNorm group sizes of the outputs) of the sampling step's layers at emb 512 / hidden 256
