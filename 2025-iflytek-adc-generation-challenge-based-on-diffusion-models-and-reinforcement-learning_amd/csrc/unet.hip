@@ -514,6 +514,16 @@ int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t
         void* raw = i < 9 ? ws.take((size_t)Bp * b.cout * e) : nullptr;
         void* n_next = ws.take((size_t)Bp * b.cout * e);
         void* n_skip = i <= 3 ? ws.take((size_t)Bp * b.cout * e) : nullptr;
+        // At most 64 rows: a GroupNorm output with 128-channel groups would force 128-column tiles on the few-row kernels (22 us per
+        // launch against 8.6 / 11.2 us with 32- / 64-column tiles and K split over workgroups).  Such an output is left to a
+        // GroupNorm launch on the float32 result instead (about 4 us); its statistics see the same float32 values.
+        const int gs_next = i < 9 ? n->blk[i + 1].gs1 : H / num_groups(H);
+        const int gs_skip = i <= 3 ? n->blk[9 - i].gs1 : 0;
+        // bf16 batches whose GEMMs may split K (float32 has no few-row kernels, and its small batches stay bit-identical to large ones);
+        // a function of B and the plan alone: the dry run sizes the workspace with it
+        const bool few = dt == ADCDIFF_BF16 && B <= 64 && debug_value(DBG_GEMM_SPLITK) != 0;
+        const bool late_next = few && gs_next > 64, late_skip = few && gs_skip > 64;
+        float* o_f32 = (late_next || late_skip) ? (float*)ws.take((size_t)Bp * b.cout * 4) : nullptr;
         if (!dry) {
             adcdiff_gemm_args g = gemm_args(dt, Bp, B, b.cout);
             g.nseg = 1; g.A[0] = a2; g.lda[0] = b.cout; g.K[0] = b.cout;
@@ -525,20 +535,21 @@ int forward_fused(adcdiff_unet* n, const float* x, int ldx, int B, const int64_t
                 g.residual = c0.raw; g.ldr = c0.C;
             }
             g.out_op = raw; g.ldo_op = b.cout;
+            if (o_f32) { g.out_f32 = o_f32; g.ldo_f32 = b.cout; }
             g.gn_eps = 1e-5f;
-            if (i < 9) {
-                const BlockPlan& nb = n->blk[i + 1];
-                g.gn[g.n_gn++] = adcdiff_gn_out{p.blocks[i + 1].norm1_w, p.blocks[i + 1].norm1_b, n_next, b.cout, nb.gs1};
-            } else {
-                g.gn[g.n_gn++] = adcdiff_gn_out{p.out_norm_w, p.out_norm_b, n_next, b.cout, H / num_groups(H)};
-            }
+            const float* const next_w = i < 9 ? p.blocks[i + 1].norm1_w : p.out_norm_w;
+            const float* const next_b = i < 9 ? p.blocks[i + 1].norm1_b : p.out_norm_b;
+            if (!late_next) g.gn[g.n_gn++] = adcdiff_gn_out{next_w, next_b, n_next, b.cout, gs_next};
+            const float *skip_w = nullptr, *skip_b = nullptr;
             if (i <= 3) {
                 const BlockPlan& db = n->blk[9 - i];
-                g.gn[g.n_gn++] = adcdiff_gn_out{p.blocks[9 - i].norm1_w + db.part_c[0], p.blocks[9 - i].norm1_b + db.part_c[0], n_skip,
-                                                b.cout, db.gs1};
+                skip_w = p.blocks[9 - i].norm1_w + db.part_c[0]; skip_b = p.blocks[9 - i].norm1_b + db.part_c[0];
+                if (!late_skip) g.gn[g.n_gn++] = adcdiff_gn_out{skip_w, skip_b, n_skip, b.cout, gs_skip};
             }
             g.splitk_scratch = sk; g.splitk_scratch_bytes = (long long)n->sk_bytes;
             TRY(gemm_dispatch(g, st));
+            if (late_next) TRY(groupnorm_silu(o_f32, b.cout, B, b.cout, b.cout / gs_next, next_w, next_b, 1e-5f, dt, n_next, b.cout, nullptr, 0, st));
+            if (late_skip) TRY(groupnorm_silu(o_f32, b.cout, B, b.cout, b.cout / gs_skip, skip_w, skip_b, 1e-5f, dt, n_skip, b.cout, nullptr, 0, st));
         }
         outs[i] = Act{raw, n_next, n_skip, b.cout};
     }

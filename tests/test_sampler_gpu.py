@@ -159,6 +159,30 @@ def test_batch_65536_bf16_rows_are_independent_of_the_tiling(golden_a):
     assert not torch.equal(bigc[:256], big[:256])
 
 
+def test_few_row_bf16_path_agrees_with_the_tile_identical_one():
+    """At most 64 rows in bf16 (the generator's batch is 32): the large layers split K over workgroups and the two GroupNorm
+    outputs with 128-channel groups (the inputs of decoder.0) come from a GroupNorm launch on the float32 layer output instead of a
+    128-column GEMM tile.  Float32 summation order differs from the large-batch kernels, nothing else: five reverse steps stay
+    within bf16 rounding of the path with the switch off, which equals the rows of a batch of 256 bit for bit; the default path
+    reproduces itself bit for bit."""
+    m, _ = build((512, 256, 512), "bf16")
+    steps = dict(t_start=999, t_stop=995)
+    dflt = m.p_sample_loop((32, 512), seed=SEED, **steps)
+    again = m.p_sample_loop((32, 512), seed=SEED, **steps)
+    assert torch.equal(dflt, again)
+    adcdiff._lib.debug_set("gemm_splitk", 0)
+    try:
+        plain = m.p_sample_loop((32, 512), seed=SEED, **steps)
+    finally:
+        adcdiff._lib.debug_set("gemm_splitk", 1)
+    big = m.p_sample_loop((256, 512), seed=SEED, **steps)
+    assert torch.equal(plain, big[:32])
+    assert not torch.equal(dflt, plain)            # the few-row kernels really ran
+    err = float((dflt - plain).abs().max()) / float(plain.abs().max())
+    print("few-row path against the tile-identical one after 5 steps: %.2e of the latents' scale" % err)
+    assert err <= 1e-3   # observed 1.1e-4
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_unfused_path_for_non_power_of_two_groups(dtype):
     """hidden_dim 192 gives GroupNorm groups of 6, 12, ... channels, which the GEMM epilogue does not take;
