@@ -1810,6 +1810,13 @@ __global__ __launch_bounds__(64) void gemm_w1s_bf16_kernel(const GemmParams p) {
     float* const xch = prm + 5 * BN;
     const int lane = threadIdx.x;
     const int S = p.sk_splits;
+#ifdef ADCDIFF_STAMPS
+    long long stamp[8] = {(long long)__builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0, 0, 0, 0};
+    auto put_stamps = [&]() {
+        if (lane == 0)
+            for (int i = 0; i < 8; ++i) p.stamps[(size_t)blockIdx.x * 8 + i] = stamp[i];
+    };
+#endif
     // workgroup -> (tile, split): the S workgroups of a tile on ONE XCD (consecutive workgroup ids go round the eight XCDs), so that
     // the last one finds the others' partials in its own L2; any other tile count takes the plain order (the fences do not care)
     int tile, sp;
@@ -1862,6 +1869,9 @@ __global__ __launch_bounds__(64) void gemm_w1s_bf16_kernel(const GemmParams p) {
     // latencies either way.
     int it = t0;
     bool first = true;
+#ifdef ADCDIFF_STAMPS
+    stamp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     while (it < t1) {
         const int nround = t1 - it < D ? t1 - it : D;
 #pragma unroll
@@ -1879,8 +1889,11 @@ __global__ __launch_bounds__(64) void gemm_w1s_bf16_kernel(const GemmParams p) {
             }
         }
         if (first) Epi::stage_params(p, n0, lane, prm);   // younger than every piece of the round
-        first = false;
         wait_vmcnt<0>();
+#ifdef ADCDIFF_STAMPS
+        if (first) stamp[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+        first = false;
         for (int t = 0; t < nround; ++t) {
             const char* const stage = smem + t * STAGE_BYTES;
             uint4 fa[2][TM], fb[2][TN];
@@ -1903,53 +1916,73 @@ __global__ __launch_bounds__(64) void gemm_w1s_bf16_kernel(const GemmParams p) {
     }
 
     // partial accumulators out, arrival count up; the last workgroup of the tile sums all S partials in split order.
-    // The exchange goes THROUGH the caches instead of flushing them: the partials are stored and loaded as relaxed system-scope
-    // atomics (write-through to / read from the memory side, 256 contiguous bytes per instruction), the stores are waited for
-    // (vmcnt) before the lane-0 increment, which is performed at the memory side as well.  A device-scope fence pair here
-    // (an L2 write-back and invalidate per workgroup) cost 6 us per launch, more than the split gains.
-    // (Device scope for the partials, which the same-XCD placement would allow, measured the same.)
-    auto exchange = [&](auto SCOPE) {
-        constexpr int SC = decltype(SCOPE)::value;
-        float* const mine = p.sk_part + (((size_t)tile * S + sp) * (TM * TN * 4)) * 64 + lane;
+    // The exchange goes THROUGH the caches instead of flushing them: the partials are stored and loaded with the system-scope cache
+    // bits (sc0 sc1: write-through to / read from the memory side), 16 bytes per lane = 1 KiB per instruction, the stores are waited
+    // for (vmcnt) before the lane-0 increment, which is performed at the memory side as well.  A device-scope fence pair here (an L2
+    // write-back and invalidate per workgroup) cost 6 us per launch, more than the split gains.  Four-byte accesses (relaxed
+    // system-scope atomics, the first form of this exchange) are bound by their instruction count: 480 loads = 4 us for the 15
+    // foreign partials of a 32 x 64 tile; with 16-byte accesses the reduction is a memory round trip per batch of loads.
+    // Layout: [tile][split][16 x 16 block][lane] float4.
+    auto exchange = [&]() {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int SC = 17;   // sc0 | sc1
+        constexpr int NB = TM * TN;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.sk_part, 0, (int)((unsigned)p.ntn * (unsigned)S * (unsigned)(NB * 1024)), 0x00020000);
+        const int voff = lane * 16;
+        const int mine = __builtin_amdgcn_readfirstlane((tile * S + sp) * (NB * 1024));
 #pragma unroll
-        for (int k = 0; k < TM * TN; ++k)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                __hip_atomic_store(mine + (k * 4 + c) * 64, acc[k / TN][k % TN][c], __ATOMIC_RELAXED, SC);
+        for (int k = 0; k < NB; ++k)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[k / TN][k % TN]), rs, voff, mine + k * 1024, SC);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every lane's partials have reached the coherence point
+#ifdef ADCDIFF_STAMPS
+        stamp[4] = __builtin_amdgcn_s_memrealtime();
+#endif
         unsigned arrived = 0;
         if (lane == 0) arrived = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+#ifdef ADCDIFF_STAMPS
+        stamp[5] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (arrived != (unsigned)(S - 1)) return false;
-        const float* const all = p.sk_part + ((size_t)tile * S * (TM * TN * 4)) * 64 + lane;
+        asm volatile("" ::: "memory");   // the loads below stay behind the increment's return
+        const int all = __builtin_amdgcn_readfirstlane(tile * S * (NB * 1024));
 #pragma unroll
-        for (int k = 0; k < TM * TN; ++k)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                acc[k / TN][k % TN][c] = __hip_atomic_load(all + (k * 4 + c) * 64, __ATOMIC_RELAXED, SC);
-        // up to four splits' loads in flight at a time (128 registers), added in split order
-        constexpr int U = 32 / (TM * TN) >= 4 ? 4 : 32 / (TM * TN) >= 1 ? 32 / (TM * TN) : 1;
+        for (int k = 0; k < NB; ++k)
+            acc[k / TN][k % TN] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, all + k * 1024, SC));
+        // batches of U splits' loads in flight (up to 256 registers of a lone wave's 512), added in split order
+        constexpr int U = 64 / NB >= 1 ? (64 / NB > 15 ? 15 : 64 / NB) : 1;
         for (int q = 1; q < S; q += U) {
-            float v[U][TM * TN * 4];
+            f32x4 v[U][NB];
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (q + u < S) {
-                    const float* const src = all + (size_t)(q + u) * (TM * TN * 4) * 64;
+                    const int src = all + (q + u) * (NB * 1024);
 #pragma unroll
-                    for (int k = 0; k < TM * TN * 4; ++k) v[u][k] = __hip_atomic_load(src + k * 64, __ATOMIC_RELAXED, SC);
+                    for (int k = 0; k < NB; ++k) v[u][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, src + k * 1024, SC));
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (q + u < S) {
 #pragma unroll
-                    for (int k = 0; k < TM * TN * 4; ++k) acc[(k / 4) / TN][(k / 4) % TN][k & 3] += v[u][k];
+                    for (int k = 0; k < NB; ++k) acc[k / TN][k % TN] += v[u][k];
                 }
         }
         if (lane == 0) __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // for the next launch
         return true;
     };
-    if (!exchange(std::integral_constant<int, __HIP_MEMORY_SCOPE_SYSTEM>{})) return;
+#ifdef ADCDIFF_STAMPS
+    stamp[3] = __builtin_amdgcn_s_memrealtime();
+    if (!exchange()) { put_stamps(); return; }
+    stamp[6] = __builtin_amdgcn_s_memrealtime();
+#else
+    if (!exchange()) return;
+#endif
     Epi::template run<true, (BN >= 64 ? 4 : 2)>(acc, p, m0, n0, 0, 0, 0, lane, reinterpret_cast<float*>(smem), prm, xch);
+#ifdef ADCDIFF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp[7] = __builtin_amdgcn_s_memrealtime();
+    put_stamps();
+#endif
 }
 
 constexpr int w1s_tiles(int bm, int bn) { return 57 / ((bm + bn) / 8) < 8 ? 57 / ((bm + bn) / 8) : 8; }
@@ -1970,7 +2003,44 @@ static int launch_w1s(const GemmParams& p, int splits, hipStream_t stream) {
     (void)D;
     if (p.m_valid > BM || splits < 2 || splits > p.nt_total)
         return fail(ADCDIFF_E_BADARG, "gemm: split-K geometry (rows %d > %d, %d splits of %d K tiles)", p.m_valid, BM, splits, p.nt_total);
+#ifdef ADCDIFF_STAMPS
+    static long long* dbuf = nullptr;
+    if (!dbuf) (void)hipMalloc(&dbuf, (size_t)8192 * 8 * 8);
+    q.stamps = dbuf;
+#endif
     hipLaunchKernelGGL((gemm_w1s_bf16_kernel<BM, BN>), dim3(q.ntn * splits), dim3(64), smem, stream, q);
+#ifdef ADCDIFF_STAMPS
+    {
+        // measurement build: every 40th launch of an instantiation is dissected (10 ns units): workgroup start after the first
+        // workgroup's, set-up, first round of loads, the rest of the K range, partial stores until acknowledged, the arrival
+        // atomic; for the finishing workgroups the reduction and the epilogue
+        static int calls = 0;
+        const int grid = q.ntn * splits;
+        if (++calls % 40 == 0 && grid <= 8192) {
+            (void)hipDeviceSynchronize();
+            std::vector<long long> h((size_t)grid * 8);
+            (void)hipMemcpy(h.data(), q.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+            long long t0 = 1LL << 62, t_end = 0, last_start = 0;
+            for (int b = 0; b < grid; ++b) {
+                const long long* o = &h[(size_t)b * 8];
+                if (o[0] < t0) t0 = o[0];
+                if (o[0] > last_start) last_start = o[0];
+                const long long e = o[7] ? o[7] : o[5];
+                if (e > t_end) t_end = e;
+            }
+            double seg[5] = {0}, fin[2] = {0}, fin_start = 0; int nfin = 0;
+            for (int b = 0; b < grid; ++b) {
+                const long long* o = &h[(size_t)b * 8];
+                seg[0] += o[1] - o[0]; seg[1] += o[2] - o[1]; seg[2] += o[3] - o[2]; seg[3] += o[4] - o[3]; seg[4] += o[5] - o[4];
+                if (o[7]) { fin[0] += o[6] - o[5]; fin[1] += o[7] - o[6]; fin_start += o[5] - t0; ++nfin; }
+            }
+            fprintf(stderr, "[stamps w1s<%d,%d>] N %d K tiles %d splits %d grid %d: first to last workgroup start %.2f us, span %.2f us; mean set-up %.2f, first round %.2f, "
+                            "rest of K %.2f, partial stores %.2f, arrival %.2f us; finishing workgroups (%d): arrive at +%.2f us, reduction %.2f, epilogue %.2f us\n",
+                    BM, BN, p.N, p.nt_total, splits, grid, (last_start - t0) / 100.0, (t_end - t0) / 100.0, seg[0] / grid / 100.0, seg[1] / grid / 100.0, seg[2] / grid / 100.0,
+                    seg[3] / grid / 100.0, seg[4] / grid / 100.0, nfin, fin_start / (nfin ? nfin : 1) / 100.0, fin[0] / (nfin ? nfin : 1) / 100.0, fin[1] / (nfin ? nfin : 1) / 100.0);
+        }
+    }
+#endif
     return check_launch("gemm (one wave per tile, K split over workgroups)");
 }
 
