@@ -2459,7 +2459,10 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
             // stream at least 4 MB of weights through tiles of 32 or 64 columns -- N = K = 2048 12.4 -> 10.3 us, N = 1024 with
             // K = 4096 / 5120 14.9 -> 9.3 / 21.5 -> 14.6 us; it loses about 1 us on the small layers (the exchange) and changes
             // nothing for the 128-column tiles (22 us either way); tile_hint 327 forces it.
-            const bool pays = bn <= 64 && p.nt_total >= 32 && (long long)a.N * ktot >= (1LL << 22);
+            // (with 32-column tiles the exchange is one batch of 16-byte loads, and the split also wins on the 512- and 256-wide layers with
+            // K >= 1280: N = 512 / K = 2560 12.7 -> 9.4 us, N = 512 / K = 2048 10.2 -> 9.4 us, N = 256 / K = 1280 8.2 -> 7.2 us; it loses below 20 K tiles)
+            const bool pays = (bn <= 64 && p.nt_total >= 32 && (long long)a.N * ktot >= (1LL << 22)) ||
+                              (bn == 32 && p.nt_total >= 20 && (long long)a.N * ktot >= (1LL << 18));
             if (a.splitk_scratch && p.m_valid <= 64 && (a.tile_hint == 327 || (a.tile_hint == 0 && pays)) && debug_value(DBG_GEMM_SPLITK) != 0) {
                 const int bm = r32 ? 32 : 64, ntn = a.N / bn;
                 int S = 256 / ntn;
