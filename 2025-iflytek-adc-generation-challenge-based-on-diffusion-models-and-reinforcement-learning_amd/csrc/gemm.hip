@@ -2391,9 +2391,9 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
         const int forced = (int)debug_value(DBG_GEMM_TILE);
         const bool enough_tiles = forced != 128 && (long)(a.M / 256) * (a.N / 256) * p.ksplit >= 192;
         // K = 256 (four K tiles) pays on the four-wave kernel unless the epilogue carries the schedule update: 69 -> 54 us for the
-        // N = 512 layer at M = 65536, but 150 -> 167 us for the output head with the update folded in
-        const bool long_k = kslice >= 512 || (kslice >= (int)debug_value(DBG_GEMM_BIG_MIN_K) && a.update.kind == 0 &&
-                                              a.N >= (int)debug_value(DBG_GEMM_W4_MIN_N));
+        // N = 512 layer at M = 65536, but 150 -> 167 us for the output head with the update folded in, which the eight-wave kernel
+        // (two waves per SIMD to hide the update's latent reads) runs in 137 us
+        const bool long_k = kslice >= 512 || (kslice >= (int)debug_value(DBG_GEMM_BIG_MIN_K) && a.N >= (int)debug_value(DBG_GEMM_W4_MIN_N));
         big = forced == 256 || forced == 2561 || a.tile_hint == 256 || a.tile_hint == 2561 || a.tile_hint == 2560 || (a.tile_hint >= 2564 && a.tile_hint <= 2568) || (enough_tiles && long_k);
         pipelined = a.tile_hint == 2561 || (a.tile_hint != 2560 && pipe_default);
     }
@@ -2412,7 +2412,7 @@ int gemm_dispatch(const adcdiff_gemm_args& a, hipStream_t stream) {
     // asks for one of the 8-wave kernels
     const bool w4_default = debug_value(DBG_GEMM_W4) != 0;
     const bool w4_hint = a.tile_hint >= 2564 && a.tile_hint <= 2568;
-    const bool w4 = big && p.ksplit == 1 && p.nt_total >= 2 &&
+    const bool w4 = big && p.ksplit == 1 && p.nt_total >= 2 && !(kslice < 512 && a.update.kind != 0) &&
                     (w4_hint || (w4_default && a.N >= (int)debug_value(DBG_GEMM_W4_MIN_N) && a.tile_hint != 2560 && a.tile_hint != 2561 && a.tile_hint != 256));
     const int kind = a.dtype == ADCDIFF_F32 ? ADCDIFF_KIND_GEMM_F32 : w4 ? ADCDIFF_KIND_GEMM_BF16_W256 : big ? ADCDIFF_KIND_GEMM_BF16_T256 : ADCDIFF_KIND_GEMM_BF16;
     TimingScope ts(kind, a.M, a.N, ktot, 2.0 * a.M * a.N * ktot,
